@@ -1,0 +1,1009 @@
+/* TEST INFRASTRUCTURE ONLY -- see boxmg.h.
+ *
+ * 3D BoxMG kernels restated in C from the reference's Fortran
+ * (src/3d/ftn/ *.f90).  1-based index macros; term order inside each sum is
+ * the reference's; compiled with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "boxmg.h"
+
+#define F3(a, II, JJ, i, j, k) \
+	(a)[(size_t)((i)-1) + (size_t)(II) * ((size_t)((j)-1) + (size_t)(JJ) * (size_t)((k)-1))]
+#define S3(a, II, JJ, KK, i, j, k, s) \
+	(a)[(size_t)((i)-1) + (size_t)(II) * ((size_t)((j)-1) + (size_t)(JJ) * ((size_t)((k)-1) + (size_t)(KK) * (size_t)(s)))]
+
+static inline real_t rmax(real_t a, real_t b) { return a > b ? a : b; }
+static inline real_t rmin(real_t a, real_t b) { return a < b ? a : b; }
+
+/* src/3d/ftn/BMG3_SymStd_SETUP_recip.f90:63-69 */
+void orc3_setup_recip(const real_t *so, real_t *sor, len_t II, len_t JJ, len_t KK)
+{
+	for (len_t k = 2; k <= KK - 1; k++)
+		for (len_t j = 2; j <= JJ - 1; j++)
+			for (len_t i = 2; i <= II - 1; i++)
+				S3(sor, II, JJ, KK, i, j, k, 1) = 1.0 / S3(so, II, JJ, KK, i, j, k, KP);
+}
+
+#define SO(i, j, k, s) S3(so, II, JJ, KK, i, j, k, s)
+#define Q(i, j, k) F3(q, II, JJ, i, j, k)
+#define QF(i, j, k) F3(qf, II, JJ, i, j, k)
+
+/* the 26 off-diagonal terms in the order of
+ * src/3d/ftn/BMG3_SymStd_relax_GS.f90:104-131 (= residual.f90:77-103) */
+#define OFFDIAG27(i, j, k) \
+	( QF(i, j, k) \
+	+ SO(i, j, k, KPW) * Q(i - 1, j, k) \
+	+ SO(i, j + 1, k, KPNW) * Q(i - 1, j + 1, k) \
+	+ SO(i, j + 1, k, KPS) * Q(i, j + 1, k) \
+	+ SO(i + 1, j + 1, k, KPSW) * Q(i + 1, j + 1, k) \
+	+ SO(i + 1, j, k, KPW) * Q(i + 1, j, k) \
+	+ SO(i + 1, j, k, KPNW) * Q(i + 1, j - 1, k) \
+	+ SO(i, j, k, KPS) * Q(i, j - 1, k) \
+	+ SO(i, j, k, KPSW) * Q(i - 1, j - 1, k) \
+	+ SO(i, j, k, KB) * Q(i, j, k - 1) \
+	+ SO(i, j, k, KBW) * Q(i - 1, j, k - 1) \
+	+ SO(i, j + 1, k, KBNW) * Q(i - 1, j + 1, k - 1) \
+	+ SO(i, j + 1, k, KBN) * Q(i, j + 1, k - 1) \
+	+ SO(i + 1, j + 1, k, KBNE) * Q(i + 1, j + 1, k - 1) \
+	+ SO(i + 1, j, k, KBE) * Q(i + 1, j, k - 1) \
+	+ SO(i + 1, j, k, KBSE) * Q(i + 1, j - 1, k - 1) \
+	+ SO(i, j, k, KBS) * Q(i, j - 1, k - 1) \
+	+ SO(i, j, k, KBSW) * Q(i - 1, j - 1, k - 1) \
+	+ SO(i, j, k + 1, KB) * Q(i, j, k + 1) \
+	+ SO(i, j, k + 1, KBE) * Q(i - 1, j, k + 1) \
+	+ SO(i, j + 1, k + 1, KBSE) * Q(i - 1, j + 1, k + 1) \
+	+ SO(i, j + 1, k + 1, KBS) * Q(i, j + 1, k + 1) \
+	+ SO(i + 1, j + 1, k + 1, KBSW) * Q(i + 1, j + 1, k + 1) \
+	+ SO(i + 1, j, k + 1, KBW) * Q(i + 1, j, k + 1) \
+	+ SO(i + 1, j, k + 1, KBNW) * Q(i + 1, j - 1, k + 1) \
+	+ SO(i, j, k + 1, KBN) * Q(i, j - 1, k + 1) \
+	+ SO(i, j, k + 1, KBNE) * Q(i - 1, j - 1, k + 1) )
+
+/* src/3d/ftn/BMG3_SymStd_relax_GS.f90:170-177 (= residual.f90:111-117) */
+#define OFFDIAG7(i, j, k) \
+	( QF(i, j, k) \
+	+ SO(i, j, k, KPW) * Q(i - 1, j, k) \
+	+ SO(i, j + 1, k, KPS) * Q(i, j + 1, k) \
+	+ SO(i + 1, j, k, KPW) * Q(i + 1, j, k) \
+	+ SO(i, j, k, KPS) * Q(i, j - 1, k) \
+	+ SO(i, j, k, KB) * Q(i, j, k - 1) \
+	+ SO(i, j, k + 1, KB) * Q(i, j, k + 1) )
+
+/* src/3d/ftn/BMG3_SymStd_relax_GS.f90:80-187.  NB the sense is opposite to 2D:
+ * UP runs colours 1..8 (7-pt: 0,1), DOWN 8..1 (:85-94, :144-153). */
+void orc3_relax_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   len_t II, len_t JJ, len_t KK, int ifd, int updown)
+{
+	int I1 = (int)II - 1, J1 = (int)JJ - 1, K1 = (int)KK - 1;
+	if (ifd != 1) {
+		int pstart = updown == BMG_UP ? 1 : 8, pend = updown == BMG_UP ? 8 : 1;
+		int pstride = updown == BMG_UP ? 1 : -1;
+		for (int pts = pstart; pts != pend + pstride; pts += pstride)
+			for (int k = 2 + ((pts - 1) / 4) % 2; k <= K1; k += 2)
+				for (int j = 2 + ((pts - 1) / 2) % 2; j <= J1; j += 2)
+					for (int i = 2 + (pts - 1) % 2; i <= I1; i += 2)
+						Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+	} else {
+		int pstart = updown == BMG_UP ? 0 : 1, pend = updown == BMG_UP ? 1 : 0;
+		int pstride = updown == BMG_UP ? 1 : -1;
+		for (int pts = pstart; pts != pend + pstride; pts += pstride)
+			for (int k = 2; k <= K1; k++)
+				for (int j = 2; j <= J1; j++)
+					for (int i = (j + k + pts) % 2 + 2; i <= I1; i += 2)
+						Q(i, j, k) = OFFDIAG7(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+	}
+}
+
+/* src/3d/ftn/BMG3_SymStd_residual.f90:67-121 */
+void orc3_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
+                   len_t II, len_t JJ, len_t KK, int ifd)
+{
+	for (len_t k = 2; k <= KK - 1; k++)
+		for (len_t j = 2; j <= JJ - 1; j++)
+			for (len_t i = 2; i <= II - 1; i++) {
+				if (ifd != 1)
+					F3(res, II, JJ, i, j, k) = OFFDIAG27(i, j, k) - SO(i, j, k, KP) * Q(i, j, k);
+				else
+					F3(res, II, JJ, i, j, k) = OFFDIAG7(i, j, k) - SO(i, j, k, KP) * Q(i, j, k);
+			}
+}
+#undef Q
+#undef QF
+#undef SO
+
+#define CI(ic, jc, kc, s) S3(ci, IIC, JJC, KKC, ic, jc, kc, s)
+#define QC(ic, jc, kc) F3(qc, IIC, JJC, ic, jc, kc)
+
+/* src/3d/ftn/BMG3_SymStd_restrict.f90:115-150 */
+void orc3_restrict(const real_t *q, real_t *qc, const real_t *ci,
+                   len_t II, len_t JJ, len_t KK, len_t IIC, len_t JJC, len_t KKC)
+{
+	(void)KK;
+#define Q(i, j, k) F3(q, II, JJ, i, j, k)
+	for (len_t kc = 2; kc <= KKC - 1; kc++) {
+		len_t k = 2 * (kc - 1);
+		for (len_t jc = 2; jc <= JJC - 1; jc++) {
+			len_t j = 2 * (jc - 1);
+			for (len_t ic = 2; ic <= IIC - 1; ic++) {
+				len_t i = 2 * (ic - 1);
+				QC(ic, jc, kc) = CI(ic, jc, kc, LXYNE) * Q(i - 1, j - 1, k)
+				                 + CI(ic, jc, kc, LXYA) * Q(i, j - 1, k)
+				                 + CI(ic + 1, jc, kc, LXYNW) * Q(i + 1, j - 1, k)
+				                 + CI(ic, jc, kc, LXYR) * Q(i - 1, j, k)
+				                 + Q(i, j, k)
+				                 + CI(ic + 1, jc, kc, LXYL) * Q(i + 1, j, k)
+				                 + CI(ic, jc + 1, kc, LXYSE) * Q(i - 1, j + 1, k)
+				                 + CI(ic, jc + 1, kc, LXYB) * Q(i, j + 1, k)
+				                 + CI(ic + 1, jc + 1, kc, LXYSW) * Q(i + 1, j + 1, k)
+				                 + CI(ic, jc, kc, LTNE) * Q(i - 1, j - 1, k - 1)
+				                 + CI(ic, jc, kc, LYZNW) * Q(i, j - 1, k - 1)
+				                 + CI(ic + 1, jc, kc, LTNW) * Q(i + 1, j - 1, k - 1)
+				                 + CI(ic, jc, kc, LXZNE) * Q(i - 1, j, k - 1)
+				                 + CI(ic, jc, kc, LXZA) * Q(i, j, k - 1)
+				                 + CI(ic + 1, jc, kc, LXZNW) * Q(i + 1, j, k - 1)
+				                 + CI(ic, jc + 1, kc, LTSE) * Q(i - 1, j + 1, k - 1)
+				                 + CI(ic, jc + 1, kc, LYZNE) * Q(i, j + 1, k - 1)
+				                 + CI(ic + 1, jc + 1, kc, LTSW) * Q(i + 1, j + 1, k - 1)
+				                 + CI(ic, jc, kc + 1, LBNE) * Q(i - 1, j - 1, k + 1)
+				                 + CI(ic, jc, kc + 1, LYZSW) * Q(i, j - 1, k + 1)
+				                 + CI(ic + 1, jc, kc + 1, LBNW) * Q(i + 1, j - 1, k + 1)
+				                 + CI(ic, jc, kc + 1, LXZSE) * Q(i - 1, j, k + 1)
+				                 + CI(ic, jc, kc + 1, LXZB) * Q(i, j, k + 1)
+				                 + CI(ic + 1, jc, kc + 1, LXZSW) * Q(i + 1, j, k + 1)
+				                 + CI(ic, jc + 1, kc + 1, LBSE) * Q(i - 1, j + 1, k + 1)
+				                 + CI(ic, jc + 1, kc + 1, LYZSE) * Q(i, j + 1, k + 1)
+				                 + CI(ic + 1, jc + 1, kc + 1, LBSW) * Q(i + 1, j + 1, k + 1);
+			}
+		}
+	}
+#undef Q
+}
+
+/* src/3d/ftn/BMG3_SymStd_interp_add.f90:88-240: res /= diag in place, then
+ * three sweeps (coarse k-planes; odd planes over C/y-edge columns; odd planes
+ * over x-edge/centre columns).  Argument order so,res as in the reference's
+ * 3D signature (src/3d/interp.cc:7-11). */
+void orc3_interp_add(real_t *q, const real_t *qc, const real_t *so, real_t *res,
+                     const real_t *ci, len_t IIC, len_t JJC, len_t KKC,
+                     len_t IIF, len_t JJF, len_t KKF)
+{
+#define Q(i, j, k) F3(q, IIF, JJF, i, j, k)
+#define RES(i, j, k) F3(res, IIF, JJF, i, j, k)
+	int iic1 = (int)IIC - 1, jjc1 = (int)JJC - 1, kkc1 = (int)KKC - 1;
+	int iicf1 = ((int)IIF - 2) / 2 + 2, jjcf1 = ((int)JJF - 2) / 2 + 2, kkcf1 = ((int)KKF - 2) / 2 + 2;
+	int i, j, k;
+	real_t a, aq;
+	(void)jjc1;
+
+	for (len_t kk = 2; kk <= KKF - 1; kk++)
+		for (len_t jj = 2; jj <= JJF - 1; jj++)
+			for (len_t ii = 2; ii <= IIF - 1; ii++)
+				RES(ii, jj, kk) = RES(ii, jj, kk) / S3(so, IIF, JJF, KKF, ii, jj, kk, KP);
+
+	k = 0;
+	for (int kc = 2; kc <= kkc1; kc++) {
+		k += 2;
+		j = 2;
+		i = 2;
+		Q(2, 2, k) = Q(2, 2, k) + QC(2, 2, kc);
+		for (int ic = 3; ic <= iicf1; ic++) {
+			i += 2;
+			Q(i, 2, k) = Q(i, 2, k) + QC(ic, 2, kc);
+			a = CI(ic, 2, kc, LXYR) * QC(ic, 2, kc)
+			    + CI(ic, 2, kc, LXYL) * QC(ic - 1, 2, kc);
+			Q(i - 1, j, k) = Q(i - 1, j, k) + a + RES(i - 1, j, k);
+		}
+		for (int jc = 3; jc <= jjcf1; jc++) {
+			j += 2;
+			i = 2;
+			Q(2, j, k) = Q(2, j, k) + QC(2, jc, kc);
+			aq = CI(2, jc, kc, LXYA) * QC(2, jc, kc)
+			     + CI(2, jc, kc, LXYB) * QC(2, jc - 1, kc);
+			Q(2, j - 1, k) = Q(2, j - 1, k) + aq + RES(2, j - 1, k);
+			for (int ic = 3; ic <= iicf1; ic++) {
+				i += 2;
+				Q(i, j, k) = Q(i, j, k) + QC(ic, jc, kc);
+				a = CI(ic, jc, kc, LXYR) * QC(ic, jc, kc)
+				    + CI(ic, jc, kc, LXYL) * QC(ic - 1, jc, kc);
+				Q(i - 1, j, k) = Q(i - 1, j, k) + a + RES(i - 1, j, k);
+				aq = CI(ic, jc, kc, LXYA) * QC(ic, jc, kc)
+				     + CI(ic, jc, kc, LXYB) * QC(ic, jc - 1, kc);
+				Q(i, j - 1, k) = Q(i, j - 1, k) + aq + RES(i, j - 1, k);
+				a = CI(ic, jc, kc, LXYSW) * QC(ic - 1, jc - 1, kc)
+				    + CI(ic, jc, kc, LXYNW) * QC(ic - 1, jc, kc)
+				    + CI(ic, jc, kc, LXYNE) * QC(ic, jc, kc)
+				    + CI(ic, jc, kc, LXYSE) * QC(ic, jc - 1, kc);
+				Q(i - 1, j - 1, k) = Q(i - 1, j - 1, k) + a + RES(i - 1, j - 1, k);
+			}
+		}
+	}
+
+	k = 1;
+	for (int kc = 3; kc <= kkcf1; kc++) {
+		k += 2;
+		j = 2;
+		int jc = 2;
+		i = 0;
+		for (int ic = 2; ic <= iic1; ic++) {
+			i += 2;
+			Q(i, j, k) = Q(i, j, k) + CI(ic, jc, kc, LXZA) * QC(ic, jc, kc)
+			             + CI(ic, jc, kc, LXZB) * QC(ic, jc, kc - 1) + RES(i, j, k);
+		}
+		j = 2;
+		for (jc = 3; jc <= jjcf1; jc++) {
+			j += 2;
+			i = 0;
+			for (int ic = 2; ic <= iic1; ic++) {
+				i += 2;
+				Q(i, j, k) = Q(i, j, k)
+				             + CI(ic, jc, kc, LXZA) * QC(ic, jc, kc)
+				             + CI(ic, jc, kc, LXZB) * QC(ic, jc, kc - 1)
+				             + RES(i, j, k);
+				Q(i, j - 1, k) = Q(i, j - 1, k)
+				                 + CI(ic, jc, kc, LYZNW) * QC(ic, jc, kc)
+				                 + CI(ic, jc, kc, LYZNE) * QC(ic, jc - 1, kc)
+				                 + CI(ic, jc, kc, LYZSW) * QC(ic, jc, kc - 1)
+				                 + CI(ic, jc, kc, LYZSE) * QC(ic, jc - 1, kc - 1)
+				                 + RES(i, j - 1, k);
+			}
+		}
+	}
+
+	k = 1;
+	for (int kc = 3; kc <= kkcf1; kc++) {
+		k += 2;
+		j = 2;
+		int jc = 2;
+		i = 1;
+		for (int ic = 3; ic <= iicf1; ic++) {
+			i += 2;
+			Q(i, j, k) = Q(i, j, k)
+			             + CI(ic, jc, kc, LXZNW) * QC(ic - 1, jc, kc)
+			             + CI(ic, jc, kc, LXZNE) * QC(ic, jc, kc)
+			             + CI(ic, jc, kc, LXZSW) * QC(ic - 1, jc, kc - 1)
+			             + CI(ic, jc, kc, LXZSE) * QC(ic, jc, kc - 1)
+			             + RES(i, j, k);
+		}
+		j = 2;
+		for (jc = 3; jc <= jjcf1; jc++) {
+			j += 2;
+			i = 1;
+			for (int ic = 3; ic <= iicf1; ic++) {
+				i += 2;
+				Q(i, j, k) = Q(i, j, k)
+				             + CI(ic, jc, kc, LXZNW) * QC(ic - 1, jc, kc)
+				             + CI(ic, jc, kc, LXZNE) * QC(ic, jc, kc)
+				             + CI(ic, jc, kc, LXZSW) * QC(ic - 1, jc, kc - 1)
+				             + CI(ic, jc, kc, LXZSE) * QC(ic, jc, kc - 1)
+				             + RES(i, j, k);
+				Q(i, j - 1, k) = Q(i, j - 1, k)
+				                 + CI(ic, jc, kc, LTNW) * QC(ic - 1, jc, kc)
+				                 + CI(ic, jc, kc, LTNE) * QC(ic, jc, kc)
+				                 + CI(ic, jc, kc, LTSW) * QC(ic - 1, jc - 1, kc)
+				                 + CI(ic, jc, kc, LTSE) * QC(ic, jc - 1, kc)
+				                 + CI(ic, jc, kc, LBNW) * QC(ic - 1, jc, kc - 1)
+				                 + CI(ic, jc, kc, LBNE) * QC(ic, jc, kc - 1)
+				                 + CI(ic, jc, kc, LBSW) * QC(ic - 1, jc - 1, kc - 1)
+				                 + CI(ic, jc, kc, LBSE) * QC(ic, jc - 1, kc - 1)
+				                 + RES(i, j - 1, k);
+			}
+		}
+	}
+#undef Q
+#undef RES
+}
+
+/* lumping switch, src/3d/ftn/BMG3_SymStd_SETUP_interp_OI.f90:146-148 */
+static inline real_t lump(real_t off, real_t diag, real_t s, real_t ep, real_t emach)
+{
+	return off + (diag - s) * rmax(diag - (1.0 + ep) * s, 0.0) / (fabs(diag - (1.0 + ep) * s) + emach);
+}
+
+static inline real_t min4(real_t a, real_t b, real_t c, real_t d) { return rmin(rmin(a, b), rmin(c, d)); }
+
+/* src/3d/ftn/BMG3_SymStd_SETUP_interp_OI.f90:120-538 (27-pt), :539-807 (7-pt);
+ * non-periodic.  eMACH = 1e-13 (:78).  The reference's scratch yo() only holds
+ * two scalars per point in the last phase; locals are used instead. */
+void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
+                       len_t IIC, len_t JJC, len_t KKC, int ifd)
+{
+#define SO(i, j, k, s) S3(so, IIF, JJF, KKF, i, j, k, s)
+#define CW(ic, jc, kc, s) S3(ci, IIC, JJC, KKC, ic, jc, kc, s)
+	const real_t eMACH = 1.e-13;
+	int iic1 = (int)IIC - 1, jjc1 = (int)JJC - 1, kkc1 = (int)KKC - 1;
+	int iicf1 = ((int)IIF - 2) / 2 + 2, jjcf1 = ((int)JJF - 2) / 2 + 2, kkcf1 = ((int)KKF - 2) / 2 + 2;
+	real_t a, b, c, ep, dnw, dn, dne, dw, de, dsw, ds, dse, dp, sum;
+
+	/* (1) x-edges on coarse k-planes, coarse rows (:133-161 / :548-566) */
+	for (int kc = 2; kc <= kkc1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 2; jc <= jjc1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 3; ic <= iicf1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i - 1, j, k, KP);
+				if (ifd != 1) {
+					a = SO(i - 1, j + 1, k, KPNW) + SO(i - 1, j, k, KPW)
+					    + SO(i - 1, j, k, KPSW)
+					    + SO(i - 1, j + 1, k, KBNW) + SO(i - 1, j, k, KBW)
+					    + SO(i - 1, j, k, KBSW) + SO(i - 1, j + 1, k + 1, KBSE)
+					    + SO(i - 1, j, k + 1, KBE) + SO(i - 1, j, k + 1, KBNE);
+					b = SO(i, j + 1, k, KPSW) + SO(i, j, k, KPW) + SO(i, j, k, KPNW)
+					    + SO(i, j + 1, k, KBNE) + SO(i, j, k, KBE) + SO(i, j, k, KBSE)
+					    + SO(i, j + 1, k + 1, KBSW) + SO(i, j, k + 1, KBW)
+					    + SO(i, j, k + 1, KBNW);
+					c = a + b + SO(i - 1, j, k, KPS) + SO(i - 1, j + 1, k, KPS)
+					    + SO(i - 1, j + 1, k, KBN) + SO(i - 1, j, k, KB)
+					    + SO(i - 1, j, k, KBS)
+					    + SO(i - 1, j + 1, k + 1, KBS) + SO(i - 1, j, k + 1, KB)
+					    + SO(i - 1, j, k + 1, KBN);
+					ep = rmin(fabs(a / d), fabs(b / d));
+				} else {
+					a = SO(i - 1, j, k, KPW);
+					b = SO(i, j, k, KPW);
+					ep = rmin(fabs(a / d), fabs(b) / d);
+					c = a + b + SO(i - 1, j, k, KPS) + SO(i - 1, j + 1, k, KPS)
+					    + SO(i - 1, j, k, KB) + SO(i - 1, j, k + 1, KB);
+				}
+				c = lump(a + b, d, c, ep, eMACH);
+				CW(ic, jc, kc, LXYL) = a / c;
+				CW(ic, jc, kc, LXYR) = b / c;
+			}
+		}
+	}
+	/* (2) y-edges on coarse k-planes (:166-196 / :571-589) */
+	for (int kc = 2; kc <= kkc1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 3; jc <= jjcf1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 2; ic <= iic1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i, j - 1, k, KP);
+				if (ifd != 1) {
+					a = SO(i, j, k, KPNW) + SO(i, j, k, KPS) + SO(i + 1, j, k, KPSW)
+					    + SO(i, j, k, KBNW) + SO(i, j, k, KBN) + SO(i + 1, j, k, KBNE)
+					    + SO(i, j, k + 1, KBSE) + SO(i, j, k + 1, KBS)
+					    + SO(i + 1, j, k + 1, KBSW);
+					b = SO(i, j - 1, k, KPSW) + SO(i, j - 1, k, KPS)
+					    + SO(i + 1, j - 1, k, KPNW)
+					    + SO(i, j - 1, k, KBSW) + SO(i, j - 1, k, KBS)
+					    + SO(i + 1, j - 1, k, KBSE) + SO(i, j - 1, k + 1, KBNE)
+					    + SO(i, j - 1, k + 1, KBN) + SO(i + 1, j - 1, k + 1, KBNW);
+					ep = rmin(fabs(a / d), fabs(b / d));
+					c = a + b + SO(i, j - 1, k, KPW) + SO(i + 1, j - 1, k, KPW)
+					    + SO(i, j - 1, k, KBW) + SO(i, j - 1, k, KB)
+					    + SO(i + 1, j - 1, k, KBE)
+					    + SO(i, j - 1, k + 1, KBE) + SO(i, j - 1, k + 1, KB)
+					    + SO(i + 1, j - 1, k + 1, KBW);
+				} else {
+					a = SO(i, j, k, KPS);
+					b = SO(i, j - 1, k, KPS);
+					c = a + b + SO(i, j - 1, k, KPW) + SO(i + 1, j - 1, k, KPW)
+					    + SO(i, j - 1, k, KB) + SO(i, j - 1, k + 1, KB);
+					ep = rmin(fabs(a / d), fabs(b / d));
+				}
+				c = lump(a + b, d, c, ep, eMACH);
+				CW(ic, jc, kc, LXYA) = a / c;
+				CW(ic, jc, kc, LXYB) = b / c;
+			}
+		}
+	}
+	/* (3) z-edges (:201-229 / :594-612) */
+	for (int kc = 3; kc <= kkcf1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 2; jc <= jjc1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 2; ic <= iic1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i, j, k - 1, KP);
+				if (ifd != 1) {
+					a = SO(i, j + 1, k, KBSE) + SO(i, j + 1, k, KBS)
+					    + SO(i + 1, j + 1, k, KBSW)
+					    + SO(i, j, k, KBE) + SO(i, j, k, KB) + SO(i + 1, j, k, KBW)
+					    + SO(i, j, k, KBNE) + SO(i, j, k, KBN) + SO(i + 1, j, k, KBNW);
+					b = SO(i, j + 1, k - 1, KBNW) + SO(i, j + 1, k - 1, KBN)
+					    + SO(i + 1, j + 1, k - 1, KBNE) + SO(i, j, k - 1, KBW)
+					    + SO(i, j, k - 1, KB) + SO(i + 1, j, k - 1, KBE)
+					    + SO(i, j, k - 1, KBSW) + SO(i, j, k - 1, KBS)
+					    + SO(i + 1, j, k - 1, KBSE);
+					c = a + b + SO(i, j, k - 1, KPW) + SO(i + 1, j, k - 1, KPW)
+					    + SO(i, j + 1, k - 1, KPNW) + SO(i, j + 1, k - 1, KPS)
+					    + SO(i + 1, j + 1, k - 1, KPSW) + SO(i, j, k - 1, KPSW)
+					    + SO(i, j, k - 1, KPS) + SO(i + 1, j, k - 1, KPNW);
+				} else {
+					a = SO(i, j, k, KB);
+					b = SO(i, j, k - 1, KB);
+					c = a + b + SO(i, j, k - 1, KPW) + SO(i + 1, j, k - 1, KPW)
+					    + SO(i, j + 1, k - 1, KPS) + SO(i, j, k - 1, KPS);
+				}
+				ep = rmin(fabs(a / d), fabs(b / d));
+				c = lump(a + b, d, c, ep, eMACH);
+				CW(ic, jc, kc, LXZA) = a / c;
+				CW(ic, jc, kc, LXZB) = b / c;
+			}
+		}
+	}
+	/* (4) xy-face centres on coarse k-planes (:235-281 / :618-650) */
+	for (int kc = 2; kc <= kkc1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 3; jc <= jjcf1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 3; ic <= iicf1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i - 1, j - 1, k, KP);
+				if (ifd != 1) {
+					dnw = SO(i - 1, j, k, KPNW) + SO(i - 1, j, k, KBNW)
+					      + SO(i - 1, j, k + 1, KBSE);
+					dn = SO(i - 1, j, k, KPS) + SO(i - 1, j, k, KBN)
+					     + SO(i - 1, j, k + 1, KBS);
+					dne = SO(i, j, k, KPSW) + SO(i, j, k, KBNE) + SO(i, j, k + 1, KBSW);
+					dw = SO(i - 1, j - 1, k, KPW) + SO(i - 1, j - 1, k, KBW)
+					     + SO(i - 1, j - 1, k + 1, KBE);
+					de = SO(i, j - 1, k, KPW) + SO(i, j - 1, k, KBE)
+					     + SO(i, j - 1, k + 1, KBW);
+					dsw = SO(i - 1, j - 1, k, KPSW) + SO(i - 1, j - 1, k, KBSW)
+					      + SO(i - 1, j - 1, k + 1, KBNE);
+					ds = SO(i - 1, j - 1, k, KPS) + SO(i - 1, j - 1, k, KBS)
+					     + SO(i - 1, j - 1, k + 1, KBN);
+					dse = SO(i, j - 1, k, KPNW) + SO(i, j - 1, k, KBSE)
+					      + SO(i, j - 1, k + 1, KBNW);
+					ep = min4(fabs((dsw + dw + dnw) / d), fabs((dnw + dn + dne) / d),
+					          fabs((dne + de + dse) / d), fabs((dse + ds + dsw) / d));
+					dp = dw + dnw + dn + dne + de + dse + ds + dsw;
+				} else {
+					dn = SO(i - 1, j, k, KPS);
+					dw = SO(i - 1, j - 1, k, KPW);
+					de = SO(i, j - 1, k, KPW);
+					ds = SO(i - 1, j - 1, k, KPS);
+					dnw = dne = dsw = dse = 0.0;
+					dp = dw + dn + de + ds;
+					ep = min4(fabs(dw / d), fabs(dn / d), fabs(de / d), fabs(ds / d));
+				}
+				sum = d - SO(i - 1, j - 1, k, KB) - SO(i - 1, j - 1, k + 1, KB);
+				dp = lump(dp, sum, dp, ep, eMACH);
+				dp = 1.0 / dp;
+				if (ifd != 1) {
+					CW(ic, jc, kc, LXYNW) = dp * (dnw + CW(ic - 1, jc, kc, LXYA) * dw
+					                              + CW(ic, jc, kc, LXYL) * dn);
+					CW(ic, jc, kc, LXYNE) = dp * (dne + CW(ic, jc, kc, LXYR) * dn
+					                              + CW(ic, jc, kc, LXYA) * de);
+					CW(ic, jc, kc, LXYSE) = dp * (dse + CW(ic, jc, kc, LXYB) * de
+					                              + CW(ic, jc - 1, kc, LXYR) * ds);
+					CW(ic, jc, kc, LXYSW) = dp * (dsw + CW(ic, jc - 1, kc, LXYL) * ds
+					                              + CW(ic - 1, jc, kc, LXYB) * dw);
+				} else {
+					CW(ic, jc, kc, LXYNW) = dp * (CW(ic - 1, jc, kc, LXYA) * dw
+					                              + CW(ic, jc, kc, LXYL) * dn);
+					CW(ic, jc, kc, LXYNE) = dp * (CW(ic, jc, kc, LXYR) * dn
+					                              + CW(ic, jc, kc, LXYA) * de);
+					CW(ic, jc, kc, LXYSE) = dp * (CW(ic, jc, kc, LXYB) * de
+					                              + CW(ic, jc - 1, kc, LXYR) * ds);
+					CW(ic, jc, kc, LXYSW) = dp * (CW(ic, jc - 1, kc, LXYL) * ds
+					                              + CW(ic - 1, jc, kc, LXYB) * dw);
+				}
+			}
+		}
+	}
+	/* (5) xz-face centres on coarse j-planes (:287-332 / :656-688) */
+	for (int kc = 3; kc <= kkcf1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 2; jc <= jjc1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 3; ic <= iicf1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i - 1, j, k - 1, KP);
+				if (ifd != 1) {
+					dnw = SO(i - 1, j + 1, k, KBSE) + SO(i - 1, j, k, KBE)
+					      + SO(i - 1, j, k, KBNE);
+					dn = SO(i - 1, j + 1, k, KBS) + SO(i - 1, j, k, KB) + SO(i - 1, j, k, KBN);
+					dne = SO(i, j + 1, k, KBSW) + SO(i, j, k, KBW) + SO(i, j, k, KBNW);
+					dw = SO(i - 1, j + 1, k - 1, KPNW) + SO(i - 1, j, k - 1, KPW)
+					     + SO(i - 1, j, k - 1, KPSW);
+					de = SO(i, j + 1, k - 1, KPSW) + SO(i, j, k - 1, KPW)
+					     + SO(i, j, k - 1, KPNW);
+					dsw = SO(i - 1, j + 1, k - 1, KBNW) + SO(i - 1, j, k - 1, KBW)
+					      + SO(i - 1, j, k - 1, KBSW);
+					ds = SO(i - 1, j + 1, k - 1, KBN) + SO(i - 1, j, k - 1, KB)
+					     + SO(i - 1, j, k - 1, KBS);
+					dse = SO(i, j + 1, k - 1, KBNE) + SO(i, j, k - 1, KBE)
+					      + SO(i, j, k - 1, KBSE);
+					ep = min4(fabs((dsw + dw + dnw) / d), fabs((dnw + dn + dne) / d),
+					          fabs((dne + de + dse) / d), fabs((dse + ds + dsw) / d));
+					dp = dw + dnw + dn + dne + de + dse + ds + dsw;
+				} else {
+					dn = SO(i - 1, j, k, KB);
+					dw = SO(i - 1, j, k - 1, KPW);
+					de = SO(i, j, k - 1, KPW);
+					ds = SO(i - 1, j, k - 1, KB);
+					dnw = dne = dsw = dse = 0.0;
+					dp = dw + dn + de + ds;
+					ep = min4(fabs(dw / d), fabs(dn / d), fabs(de / d), fabs(ds / d));
+				}
+				sum = d - SO(i - 1, j + 1, k - 1, KPS) - SO(i - 1, j, k - 1, KPS);
+				dp = lump(dp, sum, dp, ep, eMACH);
+				dp = 1.0 / dp;
+				if (ifd != 1) {
+					CW(ic, jc, kc, LXZNW) = dp * (dnw + CW(ic - 1, jc, kc, LXZA) * dw
+					                              + CW(ic, jc, kc, LXYL) * dn);
+					CW(ic, jc, kc, LXZNE) = dp * (dne + CW(ic, jc, kc, LXYR) * dn
+					                              + CW(ic, jc, kc, LXZA) * de);
+					CW(ic, jc, kc, LXZSE) = dp * (dse + CW(ic, jc, kc, LXZB) * de
+					                              + CW(ic, jc, kc - 1, LXYR) * ds);
+					CW(ic, jc, kc, LXZSW) = dp * (dsw + CW(ic, jc, kc - 1, LXYL) * ds
+					                              + CW(ic - 1, jc, kc, LXZB) * dw);
+				} else {
+					CW(ic, jc, kc, LXZNW) = dp * (CW(ic - 1, jc, kc, LXZA) * dw
+					                              + CW(ic, jc, kc, LXYL) * dn);
+					CW(ic, jc, kc, LXZNE) = dp * (CW(ic, jc, kc, LXYR) * dn
+					                              + CW(ic, jc, kc, LXZA) * de);
+					CW(ic, jc, kc, LXZSE) = dp * (CW(ic, jc, kc, LXZB) * de
+					                              + CW(ic, jc, kc - 1, LXYR) * ds);
+					CW(ic, jc, kc, LXZSW) = dp * (CW(ic, jc, kc - 1, LXYL) * ds
+					                              + CW(ic - 1, jc, kc, LXZB) * dw);
+				}
+			}
+		}
+	}
+	/* (6) yz-face centres on coarse i-planes (:338-381 / :694-726) */
+	for (int kc = 3; kc <= kkcf1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 3; jc <= jjcf1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 2; ic <= iic1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i, j - 1, k - 1, KP);
+				if (ifd != 1) {
+					dnw = SO(i, j, k, KBSE) + SO(i, j, k, KBS) + SO(i + 1, j, k, KBSW);
+					dn = SO(i, j - 1, k, KBE) + SO(i, j - 1, k, KB) + SO(i + 1, j - 1, k, KBW);
+					dne = SO(i, j - 1, k, KBNE) + SO(i, j - 1, k, KBN)
+					      + SO(i + 1, j - 1, k, KBNW);
+					dw = SO(i, j, k - 1, KPNW) + SO(i, j, k - 1, KPS)
+					     + SO(i + 1, j, k - 1, KPSW);
+					de = SO(i, j - 1, k - 1, KPSW) + SO(i, j - 1, k - 1, KPS)
+					     + SO(i + 1, j - 1, k - 1, KPNW);
+					dsw = SO(i, j, k - 1, KBNW) + SO(i, j, k - 1, KBN)
+					      + SO(i + 1, j, k - 1, KBNE);
+					ds = SO(i, j - 1, k - 1, KBW) + SO(i, j - 1, k - 1, KB)
+					     + SO(i + 1, j - 1, k - 1, KBE);
+					dse = SO(i, j - 1, k - 1, KBSW) + SO(i, j - 1, k - 1, KBS)
+					      + SO(i + 1, j - 1, k - 1, KBSE);
+					ep = min4(fabs((dsw + dw + dnw) / d), fabs((dnw + dn + dne) / d),
+					          fabs((dne + de + dse) / d), fabs((dse + ds + dsw) / d));
+					dp = dw + dnw + dn + dne + de + dse + ds + dsw;
+				} else {
+					dn = SO(i, j - 1, k, KB);
+					dw = SO(i, j, k - 1, KPS);
+					de = SO(i, j - 1, k - 1, KPS);
+					ds = SO(i, j - 1, k - 1, KB);
+					dnw = dne = dsw = dse = 0.0;
+					dp = dw + dn + de + ds;
+					ep = min4(fabs(dw / d), fabs(dn / d), fabs(de / d), fabs(ds / d));
+				}
+				sum = d - SO(i, j - 1, k - 1, KPW) - SO(i + 1, j - 1, k - 1, KPW);
+				dp = lump(dp, sum, dp, ep, eMACH);
+				dp = 1.0 / dp;
+				if (ifd != 1) {
+					CW(ic, jc, kc, LYZNW) = dp * (dnw + CW(ic, jc, kc, LXZA) * dw
+					                              + CW(ic, jc, kc, LXYA) * dn);
+					CW(ic, jc, kc, LYZNE) = dp * (dne + CW(ic, jc, kc, LXYB) * dn
+					                              + CW(ic, jc - 1, kc, LXZA) * de);
+					CW(ic, jc, kc, LYZSE) = dp * (dse + CW(ic, jc - 1, kc, LXZB) * de
+					                              + CW(ic, jc, kc - 1, LXYB) * ds);
+					CW(ic, jc, kc, LYZSW) = dp * (dsw + CW(ic, jc, kc - 1, LXYA) * ds
+					                              + CW(ic, jc, kc, LXZB) * dw);
+				} else {
+					CW(ic, jc, kc, LYZNW) = dp * (CW(ic, jc, kc, LXZA) * dw
+					                              + CW(ic, jc, kc, LXYA) * dn);
+					CW(ic, jc, kc, LYZNE) = dp * (CW(ic, jc, kc, LXYB) * dn
+					                              + CW(ic, jc - 1, kc, LXZA) * de);
+					CW(ic, jc, kc, LYZSE) = dp * (CW(ic, jc - 1, kc, LXZB) * de
+					                              + CW(ic, jc, kc - 1, LXYB) * ds);
+					CW(ic, jc, kc, LYZSW) = dp * (CW(ic, jc, kc - 1, LXYA) * ds
+					                              + CW(ic, jc, kc, LXZB) * dw);
+				}
+			}
+		}
+	}
+	/* (7) cell centres (:386-535 / :732-803).  The 27-pt ep expression is
+	 * restated exactly as written in the reference, including the two terms
+	 * that are not divided by the diagonal and the repeated kbse entry
+	 * (:409-441). */
+	for (int kc = 3; kc <= kkcf1; kc++) {
+		int k = 2 * (kc - 1);
+		for (int jc = 3; jc <= jjcf1; jc++) {
+			int j = 2 * (jc - 1);
+			for (int ic = 3; ic <= iicf1; ic++) {
+				int i = 2 * (ic - 1);
+				real_t d = SO(i - 1, j - 1, k - 1, KP);
+				real_t yp, yw;
+				if (ifd != 1) {
+					yp = SO(i - 1, j - 1, k - 1, KPW)
+					     + SO(i - 1, j, k - 1, KPNW)
+					     + SO(i - 1, j, k - 1, KPS) + SO(i, j, k - 1, KPSW)
+					     + SO(i, j - 1, k - 1, KPW)
+					     + SO(i, j - 1, k - 1, KPNW) + SO(i - 1, j - 1, k - 1, KPS)
+					     + SO(i - 1, j - 1, k - 1, KPSW) + SO(i - 1, j - 1, k - 1, KB)
+					     + SO(i - 1, j - 1, k - 1, KBW) + SO(i - 1, j, k - 1, KBNW)
+					     + SO(i - 1, j, k - 1, KBN) + SO(i, j, k - 1, KBNE)
+					     + SO(i, j - 1, k - 1, KBE)
+					     + SO(i, j - 1, k - 1, KBSE) + SO(i - 1, j - 1, k - 1, KBS)
+					     + SO(i - 1, j - 1, k - 1, KBSW) + SO(i - 1, j - 1, k, KB)
+					     + SO(i - 1, j - 1, k, KBE) + SO(i - 1, j, k, KBSE)
+					     + SO(i - 1, j, k, KBS)
+					     + SO(i, j, k, KBSW) + SO(i, j - 1, k, KBW)
+					     + SO(i, j - 1, k, KBNW)
+					     + SO(i - 1, j - 1, k, KBN) + SO(i - 1, j - 1, k, KBNE);
+					yw = min4(fabs(SO(i - 1, j - 1, k - 1, KPW)
+					               + SO(i - 1, j, k - 1, KPNW)
+					               + SO(i - 1, j, k, KBSE) + SO(i - 1, j - 1, k, KBE)
+					               + SO(i - 1, j - 1, k, KBNE)
+					               + SO(i - 1, j - 1, k - 1, KPSW) + SO(i - 1, j - 1, k - 1, KBSW)
+					               + SO(i - 1, j - 1, k - 1, KBW) + SO(i - 1, j, k - 1, KBNW))
+					              / d,
+					          fabs(SO(i, j - 1, k - 1, KPW) + SO(i, j, k - 1, KPSW)
+					               + SO(i, j, k, KBSW) + SO(i, j - 1, k, KBW)
+					               + SO(i, j - 1, k, KBNW) + SO(i, j - 1, k - 1, KPNW)
+					               + SO(i, j - 1, k - 1, KBSE)
+					               + SO(i, j - 1, k - 1, KBE) + SO(i, j, k - 1, KBNE))
+					              / d,
+					          fabs(SO(i - 1, j, k - 1, KPS) + SO(i - 1, j, k - 1, KPNW)
+					               + SO(i - 1, j, k, KBSE) + SO(i - 1, j, k, KBS)
+					               + SO(i, j, k, KBSW)
+					               + SO(i, j, k - 1, KPSW) + SO(i, j, k - 1, KBNE)
+					               + SO(i - 1, j, k - 1, KBN)
+					               + SO(i - 1, j, k - 1, KBNW)),
+					          fabs(SO(i - 1, j - 1, k - 1, KPS)
+					               + SO(i - 1, j - 1, k - 1, KPSW) + SO(i - 1, j - 1, k, KBNE)
+					               + SO(i - 1, j - 1, k, KBN) + SO(i, j - 1, k, KBNW)
+					               + SO(i, j - 1, k - 1, KPNW) + SO(i, j - 1, k - 1, KBSE)
+					               + SO(i - 1, j - 1, k - 1, KBS) + SO(i, j - 1, k - 1, KBSE))
+					              / d);
+					yw = rmin(yw,
+					          rmin(fabs(SO(i - 1, j - 1, k - 1, KB) + SO(i - 1, j - 1, k - 1, KBW)
+					                    + SO(i - 1, j, k - 1, KBNW) + SO(i - 1, j, k - 1, KBN)
+					                    + SO(i, j, k - 1, KBNE)
+					                    + SO(i, j - 1, k - 1, KBE) + SO(i, j - 1, k - 1, KBSE)
+					                    + SO(i - 1, j - 1, k - 1, KBS)
+					                    + SO(i - 1, j - 1, k - 1, KBSW)),
+					               fabs(SO(i - 1, j - 1, k, KB)
+					                    + SO(i - 1, j - 1, k, KBE) + SO(i - 1, j, k, KBSE)
+					                    + SO(i - 1, j, k, KBS)
+					                    + SO(i, j, k, KBSW) + SO(i, j - 1, k, KBW)
+					                    + SO(i, j - 1, k, KBNW)
+					                    + SO(i - 1, j - 1, k, KBN) + SO(i - 1, j - 1, k, KBNE))
+					                   / d));
+					yp = lump(yp, d, yp, yw, eMACH);
+					yp = 1.0 / yp;
+					CW(ic, jc, kc, LTNW)
+					    = yp * (SO(i - 1, j, k, KBSE)
+					            + CW(ic - 1, jc, kc, LYZNW)
+					              * SO(i - 1, j - 1, k - 1, KPW) + CW(ic - 1, jc, kc, LXZA)
+					              * SO(i - 1, j, k - 1, KPNW)
+					            + CW(ic, jc, kc, LXZNW) * SO(i - 1, j, k - 1, KPS)
+					            + CW(ic - 1, jc, kc, LXYA)
+					              * SO(i - 1, j - 1, k, KBE) + CW(ic, jc, kc, LXYL)
+					              * SO(i - 1, j, k, KBS)
+					            + CW(ic, jc, kc, LXYNW) * SO(i - 1, j - 1, k, KB));
+					CW(ic, jc, kc, LTNE)
+					    = yp * (SO(i, j, k, KBSW)
+					            + CW(ic, jc, kc, LXZNE)
+					              * SO(i - 1, j, k - 1, KPS) + CW(ic, jc, kc, LXZA)
+					              * SO(i, j, k - 1, KPSW)
+					            + CW(ic, jc, kc, LYZNW) * SO(i, j - 1, k - 1, KPW)
+					            + CW(ic, jc, kc, LXYR)
+					              * SO(i - 1, j, k, KBS) + CW(ic, jc, kc, LXYA)
+					              * SO(i, j - 1, k, KBW)
+					            + CW(ic, jc, kc, LXYNE) * SO(i - 1, j - 1, k, KB));
+					CW(ic, jc, kc, LBNW)
+					    = yp * (SO(i - 1, j, k - 1, KBNW)
+					            + CW(ic - 1, jc, kc - 1, LXYA) * SO(i - 1, j - 1, k - 1, KBW)
+					            + CW(ic, jc, kc - 1, LXYL) * SO(i - 1, j, k - 1, KBN)
+					            + CW(ic, jc, kc - 1, LXYNW) * SO(i - 1, j - 1, k - 1, KB)
+					            + CW(ic - 1, jc, kc, LYZSW) * SO(i - 1, j - 1, k - 1, KPW)
+					            + CW(ic - 1, jc, kc, LXZB) * SO(i - 1, j, k - 1, KPNW)
+					            + CW(ic, jc, kc, LXZSW) * SO(i - 1, j, k - 1, KPS));
+					CW(ic, jc, kc, LBNE)
+					    = yp * (SO(i, j, k - 1, KBNE)
+					            + CW(ic, jc, kc - 1, LXYNE)
+					              * SO(i - 1, j - 1, k - 1, KB) + CW(ic, jc, kc - 1, LXYR)
+					              * SO(i - 1, j, k - 1, KBN)
+					            + CW(ic, jc, kc - 1, LXYA) * SO(i, j - 1, k - 1, KBE)
+					            + CW(ic, jc, kc, LXZSE)
+					              * SO(i - 1, j, k - 1, KPS) + CW(ic, jc, kc, LXZB)
+					              * SO(i, j, k - 1, KPSW)
+					            + CW(ic, jc, kc, LYZSW) * SO(i, j - 1, k - 1, KPW));
+					CW(ic, jc, kc, LBSW)
+					    = yp * (SO(i - 1, j - 1, k - 1, KBSW)
+					            + CW(ic - 1, jc, kc - 1, LXYB) * SO(i - 1, j - 1, k - 1, KBW)
+					            + CW(ic, jc, kc - 1, LXYSW)
+					              * SO(i - 1, j - 1, k - 1, KB) + CW(ic, jc - 1, kc - 1, LXYL)
+					              * SO(i - 1, j - 1, k - 1, KBS) + CW(ic - 1, jc, kc, LYZSE)
+					              * SO(i - 1, j - 1, k - 1, KPW)
+					            + CW(ic, jc - 1, kc, LXZSW) * SO(i - 1, j - 1, k - 1, KPS)
+					            + CW(ic - 1, jc - 1, kc, LXZB) * SO(i - 1, j - 1, k - 1, KPSW));
+					CW(ic, jc, kc, LTSW)
+					    = yp * (SO(i - 1, j - 1, k, KBNE)
+					            + CW(ic - 1, jc, kc, LXYB) * SO(i - 1, j - 1, k, KBE)
+					            + CW(ic, jc, kc, LXYSW) * SO(i - 1, j - 1, k, KB)
+					            + CW(ic, jc - 1, kc, LXYL) * SO(i - 1, j - 1, k, KBN)
+					            + CW(ic - 1, jc, kc, LYZNE)
+					              * SO(i - 1, j - 1, k - 1, KPW) + CW(ic, jc - 1, kc, LXZNW)
+					              * SO(i - 1, j - 1, k - 1, KPS)
+					            + CW(ic - 1, jc - 1, kc, LXZA) * SO(i - 1, j - 1, k - 1, KPSW));
+					CW(ic, jc, kc, LTSE)
+					    = yp * (SO(i, j - 1, k, KBNW)
+					            + CW(ic, jc - 1, kc, LXYR)
+					              * SO(i - 1, j - 1, k, KBN) + CW(ic, jc, kc, LXYSE)
+					              * SO(i - 1, j - 1, k, KB)
+					            + CW(ic, jc, kc, LXYB) * SO(i, j - 1, k, KBW)
+					            + CW(ic, jc - 1, kc, LXZNE)
+					              * SO(i - 1, j - 1, k - 1, KPS) + CW(ic, jc, kc, LYZNE)
+					              * SO(i, j - 1, k - 1, KPW)
+					            + CW(ic, jc - 1, kc, LXZA) * SO(i, j - 1, k - 1, KPNW));
+					CW(ic, jc, kc, LBSE)
+					    = yp * (SO(i, j - 1, k - 1, KBSE)
+					            + CW(ic, jc - 1, kc - 1, LXYR) * SO(i - 1, j - 1, k - 1, KBS)
+					            + CW(ic, jc, kc - 1, LXYSE) * SO(i - 1, j - 1, k - 1, KB)
+					            + CW(ic, jc, kc - 1, LXYB) * SO(i, j - 1, k - 1, KBE)
+					            + CW(ic, jc - 1, kc, LXZSE) * SO(i - 1, j - 1, k - 1, KPS)
+					            + CW(ic, jc, kc, LYZSE) * SO(i, j - 1, k - 1, KPW)
+					            + CW(ic, jc - 1, kc, LXZB) * SO(i, j - 1, k - 1, KPNW));
+				} else {
+					dp = SO(i - 1, j - 1, k - 1, KPW) + SO(i - 1, j, k - 1, KPS)
+					     + SO(i, j - 1, k - 1, KPW) + SO(i - 1, j - 1, k - 1, KPS)
+					     + SO(i - 1, j - 1, k - 1, KB) + SO(i - 1, j - 1, k, KB);
+					ep = rmin(min4(fabs(SO(i - 1, j - 1, k - 1, KPW) / d),
+					               fabs(SO(i - 1, j, k - 1, KPS) / d),
+					               fabs(SO(i, j - 1, k - 1, KPW) / d),
+					               fabs(SO(i - 1, j - 1, k - 1, KPS) / d)),
+					          rmin(fabs(SO(i - 1, j - 1, k - 1, KB) / d),
+					               fabs(SO(i - 1, j - 1, k, KB) / d)));
+					dp = (d - dp) * rmax(d - (1.0 + ep) * dp, 0.0)
+					     / (fabs(d - (1.0 + ep) * dp) + eMACH) + dp;
+					dp = 1.0 / dp;
+					CW(ic, jc, kc, LTNW) = dp * (CW(ic - 1, jc, kc, LYZNW)
+					                             * SO(i - 1, j - 1, k - 1, KPW)
+					                             + CW(ic, jc, kc, LXZNW) * SO(i - 1, j, k - 1, KPS)
+					                             + CW(ic, jc, kc, LXYNW) * SO(i - 1, j - 1, k, KB));
+					CW(ic, jc, kc, LTNE) = dp * (CW(ic, jc, kc, LXZNE)
+					                             * SO(i - 1, j, k - 1, KPS)
+					                             + CW(ic, jc, kc, LYZNW) * SO(i, j - 1, k - 1, KPW)
+					                             + CW(ic, jc, kc, LXYNE) * SO(i - 1, j - 1, k, KB));
+					CW(ic, jc, kc, LBNW) = dp * (CW(ic, jc, kc - 1, LXYNW)
+					                             * SO(i - 1, j - 1, k - 1, KB)
+					                             + CW(ic - 1, jc, kc, LYZSW) * SO(i - 1, j - 1, k - 1, KPW)
+					                             + CW(ic, jc, kc, LXZSW) * SO(i - 1, j, k - 1, KPS));
+					CW(ic, jc, kc, LBNE) = dp * (CW(ic, jc, kc - 1, LXYNE)
+					                             * SO(i - 1, j - 1, k - 1, KB)
+					                             + CW(ic, jc, kc, LXZSE) * SO(i - 1, j, k - 1, KPS)
+					                             + CW(ic, jc, kc, LYZSW) * SO(i, j - 1, k - 1, KPW));
+					CW(ic, jc, kc, LBSW) = dp * (CW(ic, jc, kc - 1, LXYSW)
+					                             * SO(i - 1, j - 1, k - 1, KB)
+					                             + CW(ic - 1, jc, kc, LYZSE) * SO(i - 1, j - 1, k - 1, KPW)
+					                             + CW(ic, jc - 1, kc, LXZSW) * SO(i - 1, j - 1, k - 1, KPS));
+					CW(ic, jc, kc, LTSW) = dp * (CW(ic, jc, kc, LXYSW)
+					                             * SO(i - 1, j - 1, k, KB)
+					                             + CW(ic - 1, jc, kc, LYZNE) * SO(i - 1, j - 1, k - 1, KPW)
+					                             + CW(ic, jc - 1, kc, LXZNW) * SO(i - 1, j - 1, k - 1, KPS));
+					CW(ic, jc, kc, LTSE) = dp * (CW(ic, jc, kc, LXYSE)
+					                             * SO(i - 1, j - 1, k, KB)
+					                             + CW(ic, jc - 1, kc, LXZNE) * SO(i - 1, j - 1, k - 1, KPS)
+					                             + CW(ic, jc, kc, LYZNE) * SO(i, j - 1, k - 1, KPW));
+					CW(ic, jc, kc, LBSE) = dp * (CW(ic, jc, kc - 1, LXYSE)
+					                             * SO(i - 1, j - 1, k - 1, KB)
+					                             + CW(ic, jc - 1, kc, LXZSE) * SO(i - 1, j - 1, k - 1, KPS)
+					                             + CW(ic, jc, kc, LYZSE) * SO(i, j - 1, k - 1, KPW));
+				}
+			}
+		}
+	}
+#undef CW
+#undef SO
+}
+
+/* ------------------------------------------------------------------------
+ * Galerkin coarse operator, A_c = P^T A P.
+ * src/3d/ftn/BMG3_SymStd_SETUP_ITLI27_ex.f90:84-1888 (27-pt fine) and
+ * src/3d/ftn/BMG3_SymStd_SETUP_ITLI07_ex.f90:84-1005 (7-pt fine).
+ *
+ * The reference spells the triple product out as ~2900 lines of closed-form
+ * sums.  This restatement evaluates the same product generically from two
+ * tables that encode the reference's storage conventions:
+ *   - slot s of a stencil stored at P couples P+A3[s] with P+B3[s]
+ *     (read off src/3d/ftn/BMG3_SymStd_relax_GS.f90:104-131),
+ *   - the weight of coarse c at fine F(c)+d is the CI entry interp_add
+ *     applies there (src/3d/ftn/BMG3_SymStd_interp_add.f90:100-240).
+ * Same entries read, different association of the additions: agreement with
+ * the reference is to rounding (<= 1e-12 relative, tests/), not bit-for-bit.
+ * ------------------------------------------------------------------------ */
+static const int A3[14][3] = {
+	{ 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, /* kp kpw kps kb kpsw */
+	{ 0, -1, 0 },                                                    /* kpnw */
+	{ 0, 0, 0 },                                                     /* kbw */
+	{ 0, -1, 0 }, { 0, -1, 0 }, { -1, -1, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, /* kbnw kbn kbne kbe kbse */
+	{ 0, 0, 0 }, { 0, 0, 0 }                                         /* kbs kbsw */
+};
+static const int B3[14][3] = {
+	{ 0, 0, 0 }, { -1, 0, 0 }, { 0, -1, 0 }, { 0, 0, -1 }, { -1, -1, 0 },
+	{ -1, 0, 0 },
+	{ -1, 0, -1 },
+	{ -1, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, -1, -1 },
+	{ 0, -1, -1 }, { -1, -1, -1 }
+};
+
+/* interpolation slot and storage offset for the weight of coarse c at fine
+ * F(c)+(dx,dy,dz): CI(c + off, slot).  Index [dz+1][dy+1][dx+1]. */
+typedef struct { signed char slot, ox, oy, oz; } pwent;
+static const pwent PW3[3][3][3] = {
+	/* dz = -1 (fine plane below the coarse point: uses the "T"op/"A" weights of c) */
+	{ { { LTNE, 0, 0, 0 }, { LYZNW, 0, 0, 0 }, { LTNW, 1, 0, 0 } },
+	  { { LXZNE, 0, 0, 0 }, { LXZA, 0, 0, 0 }, { LXZNW, 1, 0, 0 } },
+	  { { LTSE, 0, 1, 0 }, { LYZNE, 0, 1, 0 }, { LTSW, 1, 1, 0 } } },
+	/* dz = 0 */
+	{ { { LXYNE, 0, 0, 0 }, { LXYA, 0, 0, 0 }, { LXYNW, 1, 0, 0 } },
+	  { { LXYR, 0, 0, 0 }, { -1, 0, 0, 0 }, { LXYL, 1, 0, 0 } },
+	  { { LXYSE, 0, 1, 0 }, { LXYB, 0, 1, 0 }, { LXYSW, 1, 1, 0 } } },
+	/* dz = +1 */
+	{ { { LBNE, 0, 0, 1 }, { LYZSW, 0, 0, 1 }, { LBNW, 1, 0, 1 } },
+	  { { LXZSE, 0, 0, 1 }, { LXZB, 0, 0, 1 }, { LXZSW, 1, 0, 1 } },
+	  { { LBSE, 0, 1, 1 }, { LYZSE, 0, 1, 1 }, { LBSW, 1, 1, 1 } } }
+};
+
+static inline real_t pw3(const real_t *ci, len_t IIC, len_t JJC, len_t KKC,
+                         int ic, int jc, int kc, int dx, int dy, int dz)
+{
+	const pwent *e = &PW3[dz + 1][dy + 1][dx + 1];
+	if (e->slot < 0) return 1.0;
+	return CI(ic + e->ox, jc + e->oy, kc + e->oz, e->slot);
+}
+
+/* lookup: for a fine-point offset e = g - f (26 of them) which slot couples
+ * them and where it is stored relative to f.  Built once from A3/B3. */
+static signed char OFF_SLOT[3][3][3], OFF_SX[3][3][3], OFF_SY[3][3][3], OFF_SZ[3][3][3];
+static int off_tab_ready = 0;
+static void build_off_tab(void)
+{
+	if (off_tab_ready) return;
+	for (int s = 1; s < 14; s++) {
+		int ex = B3[s][0] - A3[s][0], ey = B3[s][1] - A3[s][1], ez = B3[s][2] - A3[s][2];
+		/* f = P + A, g = P + B  => P = f - A */
+		OFF_SLOT[ez + 1][ey + 1][ex + 1] = (signed char)s;
+		OFF_SX[ez + 1][ey + 1][ex + 1] = (signed char)(-A3[s][0]);
+		OFF_SY[ez + 1][ey + 1][ex + 1] = (signed char)(-A3[s][1]);
+		OFF_SZ[ez + 1][ey + 1][ex + 1] = (signed char)(-A3[s][2]);
+		/* f = P + B, g = P + A  => P = f - B */
+		OFF_SLOT[-ez + 1][-ey + 1][-ex + 1] = (signed char)s;
+		OFF_SX[-ez + 1][-ey + 1][-ex + 1] = (signed char)(-B3[s][0]);
+		OFF_SY[-ez + 1][-ey + 1][-ex + 1] = (signed char)(-B3[s][1]);
+		OFF_SZ[-ez + 1][-ey + 1][-ex + 1] = (signed char)(-B3[s][2]);
+	}
+	OFF_SLOT[1][1][1] = 0;
+	off_tab_ready = 1;
+}
+
+void orc3_galerkin(const real_t *so, real_t *soc, const real_t *ci,
+                   len_t IIF, len_t JJF, len_t KKF, len_t IIC, len_t JJC, len_t KKC, int ifd)
+{
+#define SO(i, j, k, s) S3(so, IIF, JJF, KKF, i, j, k, s)
+	build_off_tab();
+	for (int kc = 2; kc <= (int)KKC - 1; kc++)
+		for (int jc = 2; jc <= (int)JJC - 1; jc++)
+			for (int ic = 2; ic <= (int)IIC - 1; ic++)
+				for (int s = 0; s < 14; s++) {
+					int c1[3] = { ic + A3[s][0], jc + A3[s][1], kc + A3[s][2] };
+					int c2[3] = { ic + B3[s][0], jc + B3[s][1], kc + B3[s][2] };
+					int f1o[3] = { 2 * (c1[0] - 1), 2 * (c1[1] - 1), 2 * (c1[2] - 1) };
+					int f2o[3] = { 2 * (c2[0] - 1), 2 * (c2[1] - 1), 2 * (c2[2] - 1) };
+					real_t acc = 0.0;
+					for (int dz = -1; dz <= 1; dz++)
+						for (int dy = -1; dy <= 1; dy++)
+							for (int dx = -1; dx <= 1; dx++) {
+								int fi = f1o[0] + dx, fj = f1o[1] + dy, fk = f1o[2] + dz;
+								real_t row = 0.0;
+								int any = 0;
+								for (int ez = -1; ez <= 1; ez++)
+									for (int ey = -1; ey <= 1; ey++)
+										for (int ex = -1; ex <= 1; ex++) {
+											int rx = fi + ex - f2o[0], ry = fj + ey - f2o[1], rz = fk + ez - f2o[2];
+											if (rx < -1 || rx > 1 || ry < -1 || ry > 1 || rz < -1 || rz > 1)
+												continue;
+											int slot = OFF_SLOT[ez + 1][ey + 1][ex + 1];
+											if (ifd == 1 && slot > KB) continue;
+											int si = fi + OFF_SX[ez + 1][ey + 1][ex + 1];
+											int sj = fj + OFF_SY[ez + 1][ey + 1][ex + 1];
+											int sk = fk + OFF_SZ[ez + 1][ey + 1][ex + 1];
+											if (slot == 0) { si = fi; sj = fj; sk = fk; }
+											if (si < 1 || si > (int)IIF || sj < 1 || sj > (int)JJF
+											    || sk < 1 || sk > (int)KKF)
+												continue;
+											real_t p2 = pw3(ci, IIC, JJC, KKC, c2[0], c2[1], c2[2], rx, ry, rz);
+											if (slot == 0) row += SO(si, sj, sk, KP) * p2;
+											else row -= SO(si, sj, sk, slot) * p2;
+											any = 1;
+										}
+								if (any)
+									acc += pw3(ci, IIC, JJC, KKC, c1[0], c1[1], c1[2], dx, dy, dz) * row;
+							}
+					S3(soc, IIC, JJC, KKC, ic, jc, kc, s) = (s == KP) ? acc : -acc;
+				}
+#undef SO
+}
+
+/* src/3d/ftn/BMG3_SymStd_SETUP_cg_LU.f90:111-198 */
+int orc3_setup_cg(const real_t *so, len_t II, len_t JJ, len_t KK, int nstncl,
+                  real_t *abd, len_t nabd1, len_t nabd2)
+{
+#define ABD(r, c) abd[(size_t)((r)-1) + (size_t)nabd1 * (size_t)((c)-1)]
+#define SO(i, j, k, s) S3(so, II, JJ, KK, i, j, k, s)
+	int i1 = (int)II - 1, j1 = (int)JJ - 1, k1 = (int)KK - 1, i2 = i1 - 1;
+	int ibw = i2 * j1 + 1, kl = 0;
+	int full = nstncl == 14;
+	(void)nabd2;
+	for (int k = 2; k <= k1; k++)
+		for (int j = 2; j <= j1; j++)
+			for (int i = 2; i <= i1; i++) {
+				kl++;
+				ABD(ibw + 1, kl) = SO(i, j, k, KP);
+				ABD(ibw, kl) = -SO(i, j, k, KPW);
+				ABD(ibw - i1 + 3, kl) = full ? -SO(i + 1, j, k, KPNW) : 0.0;
+				ABD(ibw - i1 + 2, kl) = -SO(i, j, k, KPS);
+				ABD(ibw - i1 + 1, kl) = full ? -SO(i, j, k, KPSW) : 0.0;
+				ABD(ibw - (j1 - 2) * i2 + 2, kl) = full ? -SO(i + 1, j + 1, k, KBNE) : 0.0;
+				ABD(ibw - (j1 - 2) * i2 + 1, kl) = full ? -SO(i, j + 1, k, KBN) : 0.0;
+				ABD(ibw - (j1 - 2) * i2, kl) = full ? -SO(i, j + 1, k, KBNW) : 0.0;
+				ABD(ibw - (j1 - 1) * i2 + 2, kl) = full ? -SO(i + 1, j, k, KBE) : 0.0;
+				ABD(ibw - (j1 - 1) * i2 + 1, kl) = -SO(i, j, k, KB);
+				ABD(ibw - (j1 - 1) * i2, kl) = full ? -SO(i, j, k, KBW) : 0.0;
+				ABD(3, kl) = full ? -SO(i + 1, j, k, KBSE) : 0.0;
+				ABD(2, kl) = full ? -SO(i, j, k, KBS) : 0.0;
+				ABD(1, kl) = full ? -SO(i, j, k, KBSW) : 0.0;
+			}
+	return orc_dpbtrf_upper(kl, ibw, abd, (int)nabd1);
+#undef SO
+#undef ABD
+}
+
+/* src/3d/ftn/BMG3_SymStd_SOLVE_cg.f90:100-150 */
+int orc3_solve_cg(real_t *q, const real_t *qf, len_t II, len_t JJ, len_t KK,
+                  const real_t *abd, real_t *bbd, len_t nabd1, len_t nabd2)
+{
+	int i1 = (int)II - 1, j1 = (int)JJ - 1, k1 = (int)KK - 1, i2 = i1 - 1;
+	int ibw = i2 * j1 + 1, kt = 0;
+	(void)nabd2;
+	for (int k = 2; k <= k1; k++)
+		for (int j = 2; j <= j1; j++)
+			for (int i = 2; i <= i1; i++)
+				bbd[kt++] = F3(qf, II, JJ, i, j, k);
+	orc_dpbtrs_upper(kt, ibw, abd, (int)nabd1, bbd);
+	kt = 0;
+	for (int k = 2; k <= k1; k++)
+		for (int j = 2; j <= j1; j++)
+			for (int i = 2; i <= i1; i++)
+				F3(q, II, JJ, i, j, k) = bbd[kt++];
+	return 0;
+}
+
+/* include/cedar/3d/grid_func.h lp_norm<2> (same loop nest as 2D, k slowest) */
+real_t orc_l2_norm3(const real_t *v, len_t II, len_t JJ, len_t KK)
+{
+	real_t result = 0;
+	for (len_t k = 2; k <= KK - 1; k++)
+		for (len_t j = 2; j <= JJ - 1; j++)
+			for (len_t i = 2; i <= II - 1; i++)
+				result += F3(v, II, JJ, i, j, k) * F3(v, II, JJ, i, j, k);
+	return sqrt(result);
+}
+
+/* src/3d/grid_func.cc inf_norm: signed value of the max-abs entry */
+real_t orc_inf_norm3(const real_t *v, len_t II, len_t JJ, len_t KK)
+{
+	real_t cmax = 0;
+	for (len_t k = 2; k <= KK - 1; k++)
+		for (len_t j = 2; j <= JJ - 1; j++)
+			for (len_t i = 2; i <= II - 1; i++)
+				if (fabs(cmax) < fabs(F3(v, II, JJ, i, j, k)))
+					cmax = F3(v, II, JJ, i, j, k);
+	return cmax;
+}

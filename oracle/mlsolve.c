@@ -1,0 +1,238 @@
+/* TEST INFRASTRUCTURE ONLY -- see boxmg.h.
+ *
+ * Restatement of the reference's multilevel orchestration for the serial
+ * solvers: level sizing and allocation (include/cedar/2d/solver.h:57-116,
+ * include/cedar/3d/solver.h:54-123), the set-up loop
+ * (include/cedar/multilevel.h:243-265), one V-cycle
+ * (include/cedar/cycle/vcycle.h:57-115) and the solve loop with its residual
+ * norms (include/cedar/multilevel.h:268-298).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "boxmg.h"
+
+typedef struct {
+	len_t nx, ny, nz;     /* interior extents */
+	len_t II, JJ, KK;     /* with ghosts (KK = 1 in 2D) */
+	int nst;              /* stencil planes of A */
+	size_t npts;
+	real_t *A;            /* owned */
+	real_t *P;            /* interpolation from this level to the finer one (levels >= 1) */
+	real_t *x, *b, *res;  /* level 0: x and b are the caller's */
+	real_t *SOR0, *SOR1;
+} orc_level;
+
+struct orc_ml {
+	int nd, nlev, relax, nrelax_pre, nrelax_post;
+	orc_level *lv;
+	real_t *ABD, *bbd;
+	len_t nabd1, nabd2;
+};
+
+static real_t *zalloc(size_t n) { return (real_t *)calloc(n ? n : 1, sizeof(real_t)); }
+
+/* include/cedar/2d/solver.h:57-73: float nxc = (nx-1)/(1<<ng) + 1 with unsigned
+ * integer division; loop while min(...) >= min_coarse */
+static int compute_num_levels(int nd, len_t nx, len_t ny, len_t nz, int min_coarse)
+{
+	int ng = 0;
+	float m;
+	do {
+		ng++;
+		float nxc = (float)((nx - 1) / (1u << ng) + 1);
+		float nyc = (float)((ny - 1) / (1u << ng) + 1);
+		m = nxc < nyc ? nxc : nyc;
+		if (nd == 3) {
+			float nzc = (float)((nz - 1) / (1u << ng) + 1);
+			m = m < nzc ? m : nzc;
+		}
+	} while (m >= (float)min_coarse);
+	return ng;
+}
+
+static void level_init(orc_level *L, int nd, len_t nx, len_t ny, len_t nz, int nst, int with_P)
+{
+	memset(L, 0, sizeof(*L));
+	L->nx = nx; L->ny = ny; L->nz = nd == 3 ? nz : 1;
+	L->II = nx + 2; L->JJ = ny + 2; L->KK = nd == 3 ? nz + 2 : 1;
+	L->nst = nst;
+	L->npts = (size_t)L->II * L->JJ * L->KK;
+	L->A = zalloc(L->npts * nst);
+	L->res = zalloc(L->npts);
+	L->SOR0 = zalloc(L->npts * 2);
+	L->SOR1 = zalloc(L->npts * 2);
+	if (with_P) {
+		L->P = zalloc(L->npts * (nd == 3 ? 26 : 8));
+		L->x = zalloc(L->npts);
+		L->b = zalloc(L->npts);
+	}
+}
+
+orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                      int relax, int nrelax_pre, int nrelax_post, int min_coarse,
+                      int num_levels)
+{
+	orc_ml *ml = (orc_ml *)calloc(1, sizeof(orc_ml));
+	ml->nd = nd; ml->relax = relax;
+	ml->nrelax_pre = nrelax_pre; ml->nrelax_post = nrelax_post;
+	int nlev = compute_num_levels(nd, nx, ny, nz, min_coarse);
+	if (num_levels > 0 && num_levels <= nlev) nlev = num_levels; /* multilevel.h:247-254 */
+	ml->nlev = nlev;
+	ml->lv = (orc_level *)calloc((size_t)nlev, sizeof(orc_level));
+
+	level_init(&ml->lv[0], nd, nx, ny, nz, nstencil, 0);
+	memcpy(ml->lv[0].A, so, ml->lv[0].npts * nstencil * sizeof(real_t));
+	/* setup_space: coarse extent = (len_t)((n-1)/2. + 1) */
+	for (int l = 1; l < nlev; l++) {
+		orc_level *F = &ml->lv[l - 1];
+		len_t nxc = (len_t)((F->nx - 1) / 2. + 1);
+		len_t nyc = (len_t)((F->ny - 1) / 2. + 1);
+		len_t nzc = nd == 3 ? (len_t)((F->nz - 1) / 2. + 1) : 1;
+		level_init(&ml->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, 1);
+	}
+	orc_level *C = &ml->lv[nlev - 1];
+	if (nd == 2) { ml->nabd1 = C->nx + 2; ml->nabd2 = C->nx * C->ny; }
+	else { ml->nabd1 = C->nx * (C->ny + 1) + 2; ml->nabd2 = C->nx * C->ny * C->nz; }
+	ml->ABD = zalloc((size_t)ml->nabd1 * ml->nabd2);
+	ml->bbd = zalloc(ml->nabd2);
+
+	/* setup loop: interp -> operator -> relax for l = 0 .. nlev-2 */
+	for (int l = 0; l < nlev - 1; l++) {
+		orc_level *F = &ml->lv[l], *K = &ml->lv[l + 1];
+		int ifd = (nd == 2) ? (F->nst == 3) : (F->nst == 4);
+		if (nd == 2) {
+			orc2_setup_interp(F->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd);
+			orc2_galerkin(F->A, K->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd);
+			switch (relax) {
+			case ORC_RELAX_POINT: orc2_setup_recip(F->A, F->SOR0, F->II, F->JJ); break;
+			case ORC_RELAX_LINE_X: orc2_setup_lines_x(F->A, F->SOR0, F->II, F->JJ); break;
+			case ORC_RELAX_LINE_Y: orc2_setup_lines_y(F->A, F->SOR0, F->II, F->JJ); break;
+			default:
+				orc2_setup_lines_x(F->A, F->SOR0, F->II, F->JJ);
+				orc2_setup_lines_y(F->A, F->SOR1, F->II, F->JJ);
+			}
+		} else {
+			orc3_setup_interp(F->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd);
+			orc3_galerkin(F->A, K->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd);
+			orc3_setup_recip(F->A, F->SOR0, F->II, F->JJ, F->KK);
+		}
+	}
+	/* setup_cg_solve (multilevel.h:95-103) */
+	if (nd == 2) orc2_setup_cg(C->A, C->II, C->JJ, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
+	else orc3_setup_cg(C->A, C->II, C->JJ, C->KK, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
+	return ml;
+}
+
+void orc_ml_destroy(orc_ml *ml)
+{
+	if (!ml) return;
+	for (int l = 0; l < ml->nlev; l++) {
+		orc_level *L = &ml->lv[l];
+		free(L->A); free(L->P); free(L->res); free(L->SOR0); free(L->SOR1);
+		if (l > 0) { free(L->x); free(L->b); }
+	}
+	free(ml->lv); free(ml->ABD); free(ml->bbd); free(ml);
+}
+
+int orc_ml_nlevels(const orc_ml *ml) { return ml->nlev; }
+
+void orc_ml_level_dims(const orc_ml *ml, int lvl, len_t *nx, len_t *ny, len_t *nz)
+{
+	*nx = ml->lv[lvl].nx; *ny = ml->lv[lvl].ny; *nz = ml->lv[lvl].nz;
+}
+
+const real_t *orc_ml_level_array(const orc_ml *ml, int lvl, const char *what, size_t *len)
+{
+	const orc_level *L = &ml->lv[lvl];
+	if (!strcmp(what, "A")) { *len = L->npts * L->nst; return L->A; }
+	if (!strcmp(what, "P")) { *len = L->P ? L->npts * (ml->nd == 3 ? 26 : 8) : 0; return L->P; }
+	if (!strcmp(what, "SOR0")) { *len = L->npts * 2; return L->SOR0; }
+	if (!strcmp(what, "SOR1")) { *len = L->npts * 2; return L->SOR1; }
+	if (!strcmp(what, "ABD")) { *len = (size_t)ml->nabd1 * ml->nabd2; return ml->ABD; }
+	*len = 0;
+	return NULL;
+}
+
+static void residual(const orc_ml *ml, const orc_level *L, const real_t *x, const real_t *b, real_t *r)
+{
+	if (ml->nd == 2) orc2_residual(L->A, b, x, r, L->II, L->JJ, L->nst == 3);
+	else orc3_residual(L->A, b, x, r, L->II, L->JJ, L->KK, L->nst == 4);
+}
+
+/* multilevel.h:165-222: pre = DOWN sweeps (line-xy: x then y), post = UP (y then x) */
+static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, int updown, int n)
+{
+	for (int it = 0; it < n; it++) {
+		if (ml->nd == 3) {
+			orc3_relax_gs(L->A, b, x, L->SOR0, L->II, L->JJ, L->KK, L->nst == 4, updown);
+			continue;
+		}
+		int ifd = L->nst == 3;
+		switch (ml->relax) {
+		case ORC_RELAX_POINT: orc2_relax_gs(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown); break;
+		case ORC_RELAX_LINE_X: orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown); break;
+		case ORC_RELAX_LINE_Y: orc2_relax_lines_y(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown); break;
+		default:
+			if (updown == BMG_DOWN) {
+				orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown);
+				orc2_relax_lines_y(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown);
+			} else {
+				orc2_relax_lines_y(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown);
+				orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown);
+			}
+		}
+	}
+}
+
+static void coarse_solve(orc_ml *ml, real_t *x, const real_t *b)
+{
+	orc_level *C = &ml->lv[ml->nlev - 1];
+	if (ml->nd == 2) orc2_solve_cg(x, b, C->II, C->JJ, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
+	else orc3_solve_cg(x, b, C->II, C->JJ, C->KK, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
+}
+
+/* vcycle.h:57-115 */
+static void ncycle(orc_ml *ml, int lvl, real_t *x, const real_t *b)
+{
+	orc_level *L = &ml->lv[lvl], *K = &ml->lv[lvl + 1];
+	smooth(ml, L, x, b, BMG_DOWN, ml->nrelax_pre);
+	residual(ml, L, x, b, L->res);
+	if (ml->nd == 2) orc2_restrict(L->res, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
+	else orc3_restrict(L->res, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK);
+	memset(K->x, 0, K->npts * sizeof(real_t)); /* coarse_x.set(0.0) */
+	if (lvl + 1 == ml->nlev - 1) coarse_solve(ml, K->x, K->b);
+	else ncycle(ml, lvl + 1, K->x, K->b);
+	if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
+	else orc3_interp_add(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK);
+	smooth(ml, L, x, b, BMG_UP, ml->nrelax_post);
+}
+
+void orc_ml_vcycle(orc_ml *ml, real_t *x, const real_t *b)
+{
+	if (ml->nlev == 1) coarse_solve(ml, x, b); /* vcycle.h:37-38 */
+	else ncycle(ml, 0, x, b);
+}
+
+static real_t l2(const orc_ml *ml, const orc_level *L, const real_t *v)
+{
+	return ml->nd == 2 ? orc_l2_norm2(v, L->II, L->JJ) : orc_l2_norm3(v, L->II, L->JJ, L->KK);
+}
+
+/* multilevel.h:277-298 */
+int orc_ml_solve(orc_ml *ml, const real_t *b, real_t *x, int maxiter, real_t tol, real_t *rel)
+{
+	orc_level *L = &ml->lv[0];
+	residual(ml, L, x, b, L->res);
+	real_t res0 = l2(ml, L, L->res);
+	rel[0] = res0;
+	int it = 0;
+	for (it = 0; it < maxiter; it++) {
+		orc_ml_vcycle(ml, x, b);
+		residual(ml, L, x, b, L->res);
+		real_t r = l2(ml, L, L->res) / res0;
+		rel[it + 1] = r;
+		if (r < tol) { it++; break; }
+	}
+	return it;
+}

@@ -1,0 +1,318 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-ends for the two CPU checkers.
+
+* ``Oracle``  : liboracle.so, the plain-C restatement (oracle/boxmg*.c).
+* ``Ref``     : oracle/_ref/libcedar_ref.so, the reference's own Fortran
+                compiled in the build container (only present where
+                /root/reference existed at build time, or where the built
+                .so travelled with the snapshot).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  Arrays are C-ordered numpy float64 whose *reversed* shape is the
+Fortran shape, i.e. a 2D stencil is (nst, JJ, II), a 3D grid function is
+(KK, JJ, II); ghosts included.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = C.POINTER(C.c_double)
+u = C.c_uint
+DOWN, UP = 0, 1
+RELAX = {"point": 0, "line-x": 1, "line-y": 2, "line-xy": 3}
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(P)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+class Oracle:
+    def __init__(self):
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        self.L = L = C.CDLL(path)
+        L.orc_l2_norm2.restype = C.c_double
+        L.orc_l2_norm3.restype = C.c_double
+        L.orc_inf_norm3.restype = C.c_double
+        L.orc_ml_create.restype = C.c_void_p
+        L.orc_ml_level_array.restype = P
+
+    # ---------------- 2D ----------------
+    def setup_recip2(self, so, sor):
+        _, JJ, II = so.shape
+        self.L.orc2_setup_recip(_p(so), _p(sor), u(II), u(JJ))
+
+    def relax2(self, so, qf, q, sor, updown):
+        nst, JJ, II = so.shape
+        self.L.orc2_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
+
+    def setup_lines2(self, so, sor, d):
+        _, JJ, II = so.shape
+        f = self.L.orc2_setup_lines_x if d == "x" else self.L.orc2_setup_lines_y
+        f(_p(so), _p(sor), u(II), u(JJ))
+
+    def relax_lines2(self, so, qf, q, sor, updown, d):
+        nst, JJ, II = so.shape
+        if d == "x":
+            self.L.orc2_relax_lines_x(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
+        else:
+            b = np.zeros(2 * JJ + II)
+            self.L.orc2_relax_lines_y(_p(so), _p(qf), _p(q), _p(sor), _p(b), u(II), u(JJ), int(nst == 3), updown)
+
+    def residual2(self, so, qf, q, res):
+        nst, JJ, II = so.shape
+        self.L.orc2_residual(_p(so), _p(qf), _p(q), _p(res), u(II), u(JJ), int(nst == 3))
+
+    def restrict2(self, q, qc, ci):
+        JJ, II = q.shape
+        JJC, IIC = qc.shape
+        self.L.orc2_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(IIC), u(JJC))
+
+    def interp_add2(self, q, qc, res, so, ci):
+        JJ, II = q.shape
+        JJC, IIC = qc.shape
+        self.L.orc2_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ))
+
+    def setup_interp2(self, so, ci):
+        nst, JJ, II = so.shape
+        _, JJC, IIC = ci.shape
+        self.L.orc2_setup_interp(_p(so), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3))
+
+    def galerkin2(self, so, soc, ci):
+        nst, JJ, II = so.shape
+        _, JJC, IIC = ci.shape
+        self.L.orc2_galerkin(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3))
+
+    def setup_cg2(self, so, abd):
+        nst, JJ, II = so.shape
+        n2, n1 = abd.shape
+        return self.L.orc2_setup_cg(_p(so), u(II), u(JJ), nst, _p(abd), u(n1), u(n2))
+
+    def solve_cg2(self, q, qf, abd):
+        JJ, II = q.shape
+        n2, n1 = abd.shape
+        bbd = np.zeros(n2)
+        self.L.orc2_solve_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2))
+
+    # ---------------- 3D ----------------
+    def setup_recip3(self, so, sor):
+        _, KK, JJ, II = so.shape
+        self.L.orc3_setup_recip(_p(so), _p(sor), u(II), u(JJ), u(KK))
+
+    def relax3(self, so, qf, q, sor, updown):
+        nst, KK, JJ, II = so.shape
+        self.L.orc3_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), updown)
+
+    def residual3(self, so, qf, q, res):
+        nst, KK, JJ, II = so.shape
+        self.L.orc3_residual(_p(so), _p(qf), _p(q), _p(res), u(II), u(JJ), u(KK), int(nst == 4))
+
+    def restrict3(self, q, qc, ci):
+        KK, JJ, II = q.shape
+        KKC, JJC, IIC = qc.shape
+        self.L.orc3_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC))
+
+    def interp_add3(self, q, qc, so, res, ci):
+        KK, JJ, II = q.shape
+        KKC, JJC, IIC = qc.shape
+        self.L.orc3_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK))
+
+    def setup_interp3(self, so, ci):
+        nst, KK, JJ, II = so.shape
+        _, KKC, JJC, IIC = ci.shape
+        self.L.orc3_setup_interp(_p(so), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4))
+
+    def galerkin3(self, so, soc, ci):
+        nst, KK, JJ, II = so.shape
+        _, KKC, JJC, IIC = ci.shape
+        self.L.orc3_galerkin(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4))
+
+    def setup_cg3(self, so, abd):
+        nst, KK, JJ, II = so.shape
+        n2, n1 = abd.shape
+        return self.L.orc3_setup_cg(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2))
+
+    def solve_cg3(self, q, qf, abd):
+        KK, JJ, II = q.shape
+        n2, n1 = abd.shape
+        bbd = np.zeros(n2)
+        self.L.orc3_solve_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2))
+
+    def l2(self, v):
+        if v.ndim == 2:
+            return self.L.orc_l2_norm2(_p(v), u(v.shape[1]), u(v.shape[0]))
+        return self.L.orc_l2_norm3(_p(v), u(v.shape[2]), u(v.shape[1]), u(v.shape[0]))
+
+    # ---------------- multilevel ----------------
+    def ml_create(self, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, num_levels=-1):
+        nd = so.ndim - 1
+        if nd == 2:
+            nst, JJ, II = so.shape
+            nx, ny, nz = II - 2, JJ - 2, 1
+        else:
+            nst, KK, JJ, II = so.shape
+            nx, ny, nz = II - 2, JJ - 2, KK - 2
+        h = self.L.orc_ml_create(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
+                                 nrelax_pre, nrelax_post, min_coarse, num_levels)
+        return MLHandle(self, h, nd)
+
+
+class MLHandle:
+    def __init__(self, orc, h, nd):
+        self.o, self.h, self.nd = orc, C.c_void_p(h), nd
+
+    def nlevels(self):
+        return self.o.L.orc_ml_nlevels(self.h)
+
+    def dims(self, lvl):
+        a, b, c = u(), u(), u()
+        self.o.L.orc_ml_level_dims(self.h, lvl, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def array(self, lvl, what):
+        n = C.c_size_t()
+        ptr = self.o.L.orc_ml_level_array(self.h, lvl, what.encode(), C.byref(n))
+        if not ptr or n.value == 0:
+            return None
+        flat = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+        if what == "ABD":
+            return flat
+        nx, ny, nz = self.dims(lvl)
+        shp = (ny + 2, nx + 2) if self.nd == 2 else (nz + 2, ny + 2, nx + 2)
+        return flat.reshape((-1,) + shp)
+
+    def vcycle(self, x, b):
+        self.o.L.orc_ml_vcycle(self.h, _p(x), _p(b))
+
+    def solve(self, b, x, maxiter=10, tol=1e-8):
+        rel = np.zeros(maxiter + 1)
+        n = self.o.L.orc_ml_solve(self.h, _p(b), _p(x), maxiter, C.c_double(tol), _p(rel))
+        return rel[: n + 1]
+
+    def close(self):
+        if self.h:
+            self.o.L.orc_ml_destroy(self.h)
+            self.h = None
+
+
+class Ref:
+    """The reference's Fortran entry points (signatures: SURVEY.md section 8b)."""
+
+    def __init__(self):
+        path = os.path.join(HERE, "_ref", "libcedar_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.L = C.CDLL(path)
+
+    def setup_recip2(self, so, sor):
+        nst, JJ, II = so.shape
+        self.L.BMG2_SymStd_SETUP_recip(_p(so), _p(sor), u(II), u(JJ), nst, 2)
+
+    def relax2(self, so, qf, q, sor, updown):
+        nst, JJ, II = so.shape
+        self.L.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, 0)
+
+    def setup_lines2(self, so, sor, d):
+        nst, JJ, II = so.shape
+        f = self.L.BMG2_SymStd_SETUP_lines_x if d == "x" else self.L.BMG2_SymStd_SETUP_lines_y
+        f(_p(so), _p(sor), u(II), u(JJ), nst, 0)
+
+    def relax_lines2(self, so, qf, q, sor, updown, d):
+        nst, JJ, II = so.shape
+        b = np.zeros(2 * JJ + II)
+        f = self.L.BMG2_SymStd_relax_lines_x if d == "x" else self.L.BMG2_SymStd_relax_lines_y
+        f(1, _p(so), _p(qf), _p(q), _p(sor), _p(b), u(II), u(JJ), 1, int(nst == 3), nst, 1, updown, 0)
+
+    def residual2(self, so, qf, q, res):
+        nst, JJ, II = so.shape
+        i = lambda v: C.byref(C.c_int(v))
+        self.L.BMG2_SymStd_residual(i(0), _p(so), _p(qf), _p(q), _p(res), C.byref(u(II)), C.byref(u(JJ)),
+                                    i(0), i(int(nst == 3)), i(nst), i(0), i(0), i(0), i(0))
+
+    def restrict2(self, q, qc, ci):
+        JJ, II = q.shape
+        JJC, IIC = qc.shape
+        self.L.BMG2_SymStd_restrict(_p(q), _p(qc), _p(ci), II, JJ, IIC, JJC, 0)
+
+    def interp_add2(self, q, qc, res, so, ci):
+        JJ, II = q.shape
+        JJC, IIC = qc.shape
+        self.L.BMG2_SymStd_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ), so.shape[0], 0)
+
+    def setup_interp2(self, so, ci):
+        nst, JJ, II = so.shape
+        _, JJC, IIC = ci.shape
+        soc = np.zeros((5, JJC, IIC))
+        self.L.BMG2_SymStd_SETUP_interp_OI(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, 0, 0)
+
+    def galerkin2(self, so, soc, ci):
+        nst, JJ, II = so.shape
+        _, JJC, IIC = ci.shape
+        self.L.BMG2_SymStd_SETUP_ITLI_ex(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, 0)
+
+    def setup_cg2(self, so, abd):
+        nst, JJ, II = so.shape
+        n2, n1 = abd.shape
+        r = lambda v: C.byref(u(v))
+        self.L.BMG2_SymStd_SETUP_cg_LU(_p(so), r(II), r(JJ), C.byref(C.c_int(nst)), _p(abd), r(n1), r(n2), C.byref(C.c_int(0)))
+
+    def solve_cg2(self, q, qf, abd):
+        JJ, II = q.shape
+        n2, n1 = abd.shape
+        bbd = np.zeros(n2)
+        self.L.BMG2_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2), 0)
+
+    def setup_recip3(self, so, sor):
+        nst, KK, JJ, II = so.shape
+        self.L.BMG3_SymStd_SETUP_recip(_p(so), _p(sor), u(II), u(JJ), u(KK), nst, 2)
+
+    def relax3(self, so, qf, q, sor, updown):
+        nst, KK, JJ, II = so.shape
+        self.L.BMG3_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), nst, 2, 1, updown, 0)
+
+    def residual3(self, so, qf, q, res):
+        nst, KK, JJ, II = so.shape
+        self.L.BMG3_SymStd_residual(1, 1, int(nst == 4), _p(q), _p(qf), _p(so), _p(res), u(II), u(JJ), u(KK), nst)
+
+    def restrict3(self, q, qc, ci):
+        KK, JJ, II = q.shape
+        KKC, JJC, IIC = qc.shape
+        self.L.BMG3_SymStd_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), 0)
+
+    def interp_add3(self, q, qc, so, res, ci):
+        KK, JJ, II = q.shape
+        KKC, JJC, IIC = qc.shape
+        self.L.BMG3_SymStd_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK), so.shape[0], 0)
+
+    def setup_interp3(self, so, ci):
+        nst, KK, JJ, II = so.shape
+        _, KKC, JJC, IIC = ci.shape
+        soc = np.zeros((14, KKC, JJC, IIC))
+        yo = np.zeros((14, 2, JJ, II))
+        self.L.BMG3_SymStd_SETUP_interp_OI(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC),
+                                           int(nst == 4), nst, 1, 0, _p(yo))
+
+    def galerkin3(self, so, soc, ci):
+        nst, KK, JJ, II = so.shape
+        _, KKC, JJC, IIC = ci.shape
+        f = self.L.BMG3_SymStd_SETUP_ITLI07_ex if nst == 4 else self.L.BMG3_SymStd_SETUP_ITLI27_ex
+        f(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), 0)
+
+    def setup_cg3(self, so, abd):
+        nst, KK, JJ, II = so.shape
+        n2, n1 = abd.shape
+        self.L.BMG3_SymStd_SETUP_cg_LU(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2), 0)
+
+    def solve_cg3(self, q, qf, abd):
+        KK, JJ, II = q.shape
+        n2, n1 = abd.shape
+        bbd = np.zeros(n2)
+        self.L.BMG3_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2), 0)

@@ -1,0 +1,189 @@
+"""Kernel-level and solve-level parity cases, written once and run against any
+implementation object that exposes the method names of oracle/pyoracle.py
+(`Ref` = the reference's Fortran, `Oracle` = the C restatement, and the
+product's ctypes front-end `cedar_amd.capi.Kernels`).
+
+`kernel_suite(impl, case)` returns {name: ndarray}; the golden files hold what
+`Ref` returned (oracle/gen_golden.py), the tests compare the others to it.
+"""
+import numpy as np
+
+import problems as pb
+
+DOWN, UP = 0, 1
+
+CASES_2D = [
+    # (name, nx, ny, nst)
+    ("r9x9_5", 9, 9, 3), ("r9x9_9", 9, 9, 5),
+    ("r16x12_5", 16, 12, 3), ("r16x12_9", 16, 12, 5),
+    ("r31x31_9", 31, 31, 5), ("r37x37_5", 37, 37, 3),
+    ("r64x48_9", 64, 48, 5), ("r7x10_9", 7, 10, 5),
+]
+CASES_3D = [
+    ("r9x9x9_7", 9, 9, 9, 4), ("r9x9x9_27", 9, 9, 9, 14),
+    ("r8x6x10_7", 8, 6, 10, 4), ("r8x6x10_27", 8, 6, 10, 14),
+    ("r12x7x9_27", 12, 7, 9, 14), ("r13x13x13_7", 13, 13, 13, 4),
+    ("r13x13x13_27", 13, 13, 13, 14),
+]
+
+
+def _seed(name):
+    return sum((i + 1) * ord(c) for i, c in enumerate(name)) % 100000
+
+
+def kernel_suite_2d(impl, case):
+    name, nx, ny, nst = case
+    sd = _seed(name)
+    g = (ny + 2, nx + 2)
+    gc = pb.coarse_shape(g)
+    so = pb.random_op(g, nst, sd)
+    qf = pb.uniform(g, sd + 1, -1, 1)
+    q0 = pb.uniform(g, sd + 2, -1, 1)
+    out = {}
+    sor = np.zeros((2,) + g)
+    impl.setup_recip2(so, sor)
+    out["recip"] = sor.copy()
+    for ud in (DOWN, UP):
+        q = q0.copy()
+        impl.relax2(so, qf, q, sor, ud)
+        impl.relax2(so, qf, q, sor, ud)
+        out[f"relax{ud}"] = q
+    r = np.zeros(g)
+    impl.residual2(so, qf, q0, r)
+    out["residual"] = r
+    for d in "xy":
+        sl = np.zeros((2,) + g)
+        impl.setup_lines2(so, sl, d)
+        out[f"setup_lines_{d}"] = sl.copy()
+        for ud in (DOWN, UP):
+            q = q0.copy()
+            impl.relax_lines2(so, qf, q, sl, ud, d)
+            out[f"relax_lines_{d}{ud}"] = q
+    ci = np.zeros((8,) + gc)
+    impl.setup_interp2(so, ci)
+    out["interp"] = ci.copy()
+    soc = np.zeros((5,) + gc)
+    impl.galerkin2(so, soc, ci)
+    out["galerkin"] = soc
+    qc = np.zeros(gc)
+    impl.restrict2(q0, qc, ci)
+    out["restrict"] = qc
+    qcx = pb.uniform(gc, sd + 3, -1, 1) * pb.interior_mask(gc)
+    q, res = q0.copy(), qf.copy()
+    impl.interp_add2(q, qcx, res, so, ci)
+    out["interp_add_q"], out["interp_add_res"] = q, res
+    if nx * ny <= 200:
+        abd = np.zeros((nx * ny, nx + 2))
+        impl.setup_cg2(so, abd)
+        out["abd"] = abd.copy()
+        x = np.zeros(g)
+        impl.solve_cg2(x, qf, abd)
+        out["solve_cg"] = x
+    return out
+
+
+def kernel_suite_3d(impl, case):
+    name, nx, ny, nz, nst = case
+    sd = _seed(name)
+    g = (nz + 2, ny + 2, nx + 2)
+    gc = pb.coarse_shape(g)
+    so = pb.random_op(g, nst, sd)
+    qf = pb.uniform(g, sd + 1, -1, 1)
+    q0 = pb.uniform(g, sd + 2, -1, 1)
+    out = {}
+    sor = np.zeros((2,) + g)
+    impl.setup_recip3(so, sor)
+    out["recip"] = sor.copy()
+    for ud in (DOWN, UP):
+        q = q0.copy()
+        impl.relax3(so, qf, q, sor, ud)
+        impl.relax3(so, qf, q, sor, ud)
+        out[f"relax{ud}"] = q
+    r = np.zeros(g)
+    impl.residual3(so, qf, q0, r)
+    out["residual"] = r
+    ci = np.zeros((26,) + gc)
+    impl.setup_interp3(so, ci)
+    out["interp"] = ci.copy()
+    soc = np.zeros((14,) + gc)
+    impl.galerkin3(so, soc, ci)
+    out["galerkin"] = soc
+    qc = np.zeros(gc)
+    impl.restrict3(q0, qc, ci)
+    out["restrict"] = qc
+    qcx = pb.uniform(gc, sd + 3, -1, 1) * pb.interior_mask(gc)
+    q, res = q0.copy(), qf.copy()
+    impl.interp_add3(q, qcx, so, res, ci)
+    out["interp_add_q"], out["interp_add_res"] = q, res
+    if nx * ny * nz <= 500:
+        abd = np.zeros((nx * ny * nz, nx * (ny + 1) + 2))
+        impl.setup_cg3(so, abd)
+        out["abd"] = abd.copy()
+        x = np.zeros(g)
+        impl.solve_cg3(x, qf, abd)
+        out["solve_cg"] = x
+    return out
+
+
+# --------------------------------------------------------------------------
+# Sweeps modelled on the reference's own relax tests
+#   test/2d/test_relax.cc:14-54  Point5: 31^2 poisson, x=1, b=0, 7 DOWN + 7 UP
+#   test/2d/test_relax.cc:57-97  Point9: 37^2 gallery::fe, 3 + 3
+#   test/3d/mpi/test_relax.cc:11-60 : 50^3 7-pt, 5 x (DOWN, UP)  (here 20^3 + 27-pt too)
+# --------------------------------------------------------------------------
+def sweep_suite(impl):
+    out = {}
+    for nm, so, n in (("point5", pb.poisson2(31, 31), 7), ("point9", pb.fe2(37, 37), 3)):
+        g = so.shape[1:]
+        sor = np.zeros((2,) + g)
+        impl.setup_recip2(so, sor)
+        x, b = np.ones(g), np.zeros(g)
+        for _ in range(n):
+            impl.relax2(so, b, x, sor, DOWN)
+        for _ in range(n):
+            impl.relax2(so, b, x, sor, UP)
+        out[nm] = x
+    for nm, so in (("point7", pb.poisson3(20, 20, 20)), ("point27", pb.fe3(20, 18, 16))):
+        g = so.shape[1:]
+        sor = np.zeros((2,) + g)
+        impl.setup_recip3(so, sor)
+        x, b = np.ones(g), np.zeros(g)
+        for _ in range(5):
+            impl.relax3(so, b, x, sor, DOWN)
+            impl.relax3(so, b, x, sor, UP)
+        out[nm] = x
+    return out
+
+
+# --------------------------------------------------------------------------
+# Full solves: residual-norm histories (multilevel.h:268-298)
+# --------------------------------------------------------------------------
+SOLVES = {
+    # name: (operator builder, rhs builder, settings)
+    "poisson5_400_v11": (lambda: pb.poisson2(400, 400), lambda: pb.rhs2(400, 400),
+                         dict(relax="point", nrelax_pre=1, nrelax_post=1)),
+    "poisson5_512_v21": (lambda: pb.poisson2(512, 512), lambda: pb.rhs2(512, 512),
+                         dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "varcoef9_513_v21": (lambda: pb.varcoef9(513, 513), lambda: pb.rhs2(513, 513),
+                         dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "varcoef9_200x120_v21": (lambda: pb.varcoef9(200, 120), lambda: pb.rhs2(200, 120),
+                             dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "aniso9_512_linexy": (lambda: pb.aniso9(512, 512), lambda: pb.rhs2(512, 512),
+                          dict(relax="line-xy", nrelax_pre=2, nrelax_post=1)),
+    "stretch5_800x200_linex": (lambda: pb.diag_diffusion2(800, 200, 1.0, 1e-2), lambda: pb.rhs2(800, 200),
+                               dict(relax="line-x", nrelax_pre=2, nrelax_post=1)),
+    "stretch5_200x800_liney": (lambda: pb.diag_diffusion2(200, 800, 1e-2, 1.0), lambda: pb.rhs2(200, 800),
+                               dict(relax="line-y", nrelax_pre=2, nrelax_post=1)),
+    "fe27_65_v21": (lambda: pb.fe3(65, 65, 65), lambda: pb.rhs3(65, 65, 65),
+                    dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "fe27_40x33x50_v21": (lambda: pb.fe3(40, 33, 50), lambda: pb.rhs3(40, 33, 50),
+                          dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "poisson7_65_v21": (lambda: pb.poisson3(65, 65, 65), lambda: pb.rhs3(65, 65, 65),
+                        dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "poisson7_64_v21": (lambda: pb.poisson3(64, 64, 64), lambda: pb.rhs3(64, 64, 64),
+                        dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+}
+
+# absolute floor (in units of ||r0||) below which residual histories of two
+# correctly-rounded implementations may differ: eps * cond-ish.  Default 1e-14.
+HIST_ATOL = {"aniso9_512_linexy": 1e-12, "stretch5_800x200_linex": 1e-12, "stretch5_200x800_liney": 1e-12}
