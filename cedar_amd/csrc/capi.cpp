@@ -1,0 +1,430 @@
+// C-ABI layer 1: the BMG2_/BMG3_SymStd_* drop-in entry points, the device
+// memory helpers and the library-wide runtime state (stream, staging pool,
+// error callback).  Declarations + reference citations: include/cedar_amd.h.
+#include "../../include/cedar_amd.h"
+#include "common.h"
+#include "stage.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+using namespace cedar_amd;
+
+// ------------------------------------------------------------------ error callback
+// The reference's kernels import print_error from the host program
+// (src/2d/ftn/ModInterface.f90:4-9).  Same contract here: a host definition wins
+// over this weak default.
+extern "C" __attribute__((weak)) void print_error(char *msg)
+{
+	fprintf(stderr, "[cedar_amd] %s\n", msg);
+}
+
+namespace cedar_amd {
+
+static hipStream_t g_stream = nullptr;
+hipStream_t current_stream() { return g_stream; }
+
+bool is_device_ptr(const void *p)
+{
+	hipPointerAttribute_t attr;
+	hipError_t e = hipPointerGetAttributes(&attr, p);
+	if (e != hipSuccess) {
+		(void)hipGetLastError(); // plain host memory: clear the sticky error
+		return false;
+	}
+	return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// tiny size-bucketed pool so that per-call staging does not hipMalloc every time
+static std::multimap<size_t, void *> g_pool;
+static size_t g_pool_bytes = 0;
+static const size_t POOL_CAP = (size_t)8 << 30;
+
+void *pool_get(size_t bytes)
+{
+	auto it = g_pool.lower_bound(bytes);
+	if (it != g_pool.end() && it->first <= bytes + bytes / 4 + 4096) {
+		void *p = it->second;
+		g_pool_bytes -= it->first;
+		g_pool.erase(it);
+		return p;
+	}
+	void *p = nullptr;
+	CEDAR_HIP_CHECK(hipMalloc(&p, bytes));
+	return p;
+}
+
+void pool_put(void *p, size_t bytes)
+{
+	// the true capacity of a recycled block is unknown; blocks are re-keyed by
+	// the size they were last requested with (always <= capacity)
+	if (g_pool_bytes + bytes > POOL_CAP) {
+		CEDAR_HIP_CHECK(hipFree(p));
+		return;
+	}
+	g_pool.emplace(bytes, p);
+	g_pool_bytes += bytes;
+}
+
+static void report(const char *msg)
+{
+	char buf[256];
+	strncpy(buf, msg, sizeof(buf) - 1);
+	buf[sizeof(buf) - 1] = 0;
+	print_error(buf);
+}
+
+static bool dirichlet(int jpn, const char *who)
+{
+	if (jpn == 0) return true;
+	char buf[200];
+	snprintf(buf, sizeof(buf), "%s: only Dirichlet boundaries (ibc = 0) are implemented on the GPU path, got %d", who, jpn);
+	report(buf);
+	return false;
+}
+
+} // namespace cedar_amd
+
+extern "C" {
+
+const char *cedar_amd_version(void) { return "cedar_amd 0.1 (gfx950)"; }
+
+// src/2d/ftn/BMG_get_bc.f90:11-22 with include/cedar/2d/ftn/BMG_parameters_c.h values
+void BMG_get_bc(int per_mask, int *ibc)
+{
+	// values: src/3d/ftn/BMG_parameters_f90.h:345-360
+	static const int bcmap[8] = { 0 /*definite*/, 2 /*per_x*/, 1 /*per_y*/, 3 /*per_xy*/,
+		                          5 /*per_z*/, 6 /*per_xz*/, 7 /*per_yz*/, 8 /*per_xyz*/ };
+	*ibc = bcmap[per_mask & 7];
+}
+
+// ------------------------------------------------------------------ memory helpers
+int cedar_amd_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	return n;
+}
+int cedar_amd_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : 1; }
+void *cedar_amd_malloc(size_t bytes)
+{
+	void *p = nullptr;
+	CEDAR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+	CEDAR_HIP_CHECK(hipMemsetAsync(p, 0, bytes, current_stream()));
+	return p;
+}
+void cedar_amd_free(void *p)
+{
+	if (p) CEDAR_HIP_CHECK(hipFree(p));
+}
+void cedar_amd_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+	CEDAR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, current_stream()));
+	CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream()));
+}
+void cedar_amd_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+	CEDAR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, current_stream()));
+	CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream()));
+}
+void cedar_amd_memcpy_d2d(void *dst, const void *src, size_t bytes)
+{
+	CEDAR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, current_stream()));
+}
+void cedar_amd_memset(void *dst, int value, size_t bytes)
+{
+	CEDAR_HIP_CHECK(hipMemsetAsync(dst, value, bytes, current_stream()));
+}
+void cedar_amd_sync(void) { CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream())); }
+void cedar_amd_set_stream(void *s) { cedar_amd::g_stream = static_cast<hipStream_t>(s); }
+void *cedar_amd_get_stream(void) { return cedar_amd::g_stream; }
+
+double cedar_amd_l2norm(const real_t *v, len_t II, len_t JJ, len_t KK)
+{
+	size_t n = (size_t)II * JJ * KK;
+	Staged sv(v, n, true, false);
+	real_t *scratch = static_cast<real_t *>(pool_get(4100 * sizeof(real_t)));
+	sumsq_interior(sv.get(), (int)II, (int)JJ, (int)KK, scratch, scratch + 4096, current_stream());
+	double ss = 0;
+	cedar_amd_memcpy_d2h(&ss, scratch + 4096, sizeof(double));
+	pool_put(scratch, 4100 * sizeof(real_t));
+	return std::sqrt(ss);
+}
+
+void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len_t nz, const double *params)
+{
+	static const int nst_of[13] = { 3, 3, 5, 0, 0, 0, 0, 0, 0, 0, 4, 4, 14 };
+	if (which < 0 || which > 12 || nst_of[which] == 0) {
+		report("cedar_amd_gallery: unknown operator");
+		return;
+	}
+	bool d3 = which >= 10;
+	size_t npts = (size_t)(nx + 2) * (ny + 2) * (d3 ? nz + 2 : 1);
+	Staged sso(so, npts * nst_of[which], false, true);
+	Staged sb(b, npts, false, true);
+	CEDAR_HIP_CHECK(hipMemsetAsync(sso.get(), 0, npts * nst_of[which] * sizeof(real_t), current_stream()));
+	if (b) CEDAR_HIP_CHECK(hipMemsetAsync(sb.get(), 0, npts * sizeof(real_t), current_stream()));
+	gallery_fill(which, sso.get(), sb.get(), (int)nx, (int)ny, d3 ? (int)nz : 1, params, current_stream());
+}
+
+// ------------------------------------------------------------------ 2D drop-ins
+void BMG2_SymStd_SETUP_recip(real_t *so, real_t *sor, len_t nx, len_t ny, int nstncl, int nsor_v)
+{
+	(void)nsor_v;
+	size_t P = (size_t)nx * ny; // nx,ny are the array extents incl. ghosts (so.len())
+	Staged sso(so, P * nstncl, true, false), ssor(sor, P * 2, true, true);
+	setup_recip(sso.get() + KO * P, ssor.get() + P, nx, ny, 1, current_stream());
+}
+
+void BMG2_SymStd_relax_GS(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, len_t II, len_t JJ,
+                          int kf, int ifd, int nstncl, int nsorv, int irelax_sym, int updown, int jpn)
+{
+	(void)nsorv;
+	if (!dirichlet(jpn, "BMG2_SymStd_relax_GS")) return;
+	size_t P = (size_t)II * JJ;
+	// reference branch: 9-point when K < KF or IFD != 1 (relax_GS.f90:89)
+	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
+	if (nst_eff > nstncl) nst_eff = nstncl;
+	// NONSYM always uses the DOWN ordering (relax_GS.f90:78-87)
+	int ud = (irelax_sym == 0) ? BMG_DOWN : updown;
+	Staged sso(SO, P * nstncl, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
+	relax2_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+}
+
+void BMG2_SymStd_residual(int *k, real_t *SO, real_t *QF, real_t *Q, real_t *RES, len_t *II, len_t *JJ,
+                          int *kf, int *ifd, int *nstncl, int *ibc, int *irelax, int *irelax_sym, int *updown)
+{
+	(void)ibc; (void)irelax; (void)irelax_sym; (void)updown;
+	size_t P = (size_t)(*II) * (*JJ);
+	int nst_eff = (*k < *kf || *ifd != 1) ? 5 : 3;
+	if (nst_eff > *nstncl) nst_eff = *nstncl;
+	Staged sso(SO, P * (*nstncl), true, false), sqf(QF, P, true, false), sq(Q, P, true, false), sr(RES, P, true, true);
+	residual2(sso.get(), sqf.get(), sq.get(), sr.get(), (int)*II, (int)*JJ, nst_eff, current_stream());
+}
+
+void BMG2_SymStd_SETUP_lines_x(real_t *SO, real_t *SOR, len_t Nx, len_t Ny, int NStncl, int JPN)
+{
+	if (!dirichlet(JPN, "BMG2_SymStd_SETUP_lines_x")) return;
+	size_t P = (size_t)Nx * Ny;
+	Staged sso(SO, P * NStncl, true, false), ssor(SOR, P * 2, true, true);
+	setup_lines_x(sso.get(), ssor.get(), (int)Nx, (int)Ny, current_stream());
+}
+
+void BMG2_SymStd_SETUP_lines_y(real_t *SO, real_t *SOR, len_t Nx, len_t Ny, int NStncl, int JPN)
+{
+	if (!dirichlet(JPN, "BMG2_SymStd_SETUP_lines_y")) return;
+	size_t P = (size_t)Nx * Ny;
+	Staged sso(SO, P * NStncl, true, false), ssor(SOR, P * 2, true, true);
+	setup_lines_y(sso.get(), ssor.get(), (int)Nx, (int)Ny, current_stream());
+}
+
+void BMG2_SymStd_relax_lines_x(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, real_t *B,
+                               len_t II, len_t JJ, int kf, int ifd, int nstencil, int irelax_sym,
+                               int updown, int jpn)
+{
+	(void)B;
+	if (!dirichlet(jpn, "BMG2_SymStd_relax_lines_x")) return;
+	size_t P = (size_t)II * JJ;
+	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
+	if (nst_eff > nstencil) nst_eff = nstencil;
+	int ud = (irelax_sym == 0) ? BMG_DOWN : updown;
+	Staged sso(SO, P * nstencil, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
+	relax_lines_x(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+}
+
+void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, real_t *B,
+                               len_t II, len_t JJ, int kf, int ifd, int nstencil, int irelax_sym,
+                               int updown, int jpn)
+{
+	(void)B; // the reference's per-line scratch; the device kernel keeps lines in registers/LDS
+	if (!dirichlet(jpn, "BMG2_SymStd_relax_lines_y")) return;
+	size_t P = (size_t)II * JJ;
+	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
+	if (nst_eff > nstencil) nst_eff = nstencil;
+	int ud = (irelax_sym == 0) ? BMG_DOWN : updown;
+	Staged sso(SO, P * nstencil, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
+	relax_lines_y(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+}
+
+void BMG2_SymStd_restrict(real_t *Q, real_t *QC, real_t *CI, int Nx, int Ny, int Nxc, int Nyc, int jpn)
+{
+	if (!dirichlet(jpn, "BMG2_SymStd_restrict")) return;
+	size_t P = (size_t)Nx * Ny, PC = (size_t)Nxc * Nyc;
+	Staged sq(Q, P, true, false), sqc(QC, PC, true, true), sci(CI, PC * 8, true, false);
+	restrict2(sq.get(), sqc.get(), sci.get(), Nx, Ny, Nxc, Nyc, current_stream());
+}
+
+void BMG2_SymStd_interp_add(real_t *Q, real_t *QC, real_t *RES, real_t *SO, real_t *CI,
+                            len_t IIC, len_t JJC, len_t IIF, len_t JJF, int nstncl, int jpn)
+{
+	if (!dirichlet(jpn, "BMG2_SymStd_interp_add")) return;
+	size_t P = (size_t)IIF * JJF, PC = (size_t)IIC * JJC;
+	Staged sq(Q, P, true, true), sqc(QC, PC, true, false), sr(RES, P, true, true),
+	    sso(SO, P * nstncl, true, false), sci(CI, PC * 8, true, false);
+	interp_add2(sq.get(), sqc.get(), sr.get(), sso.get(), sci.get(), (int)IIC, (int)JJC, (int)IIF, (int)JJF, current_stream());
+}
+
+void BMG2_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf,
+                                 len_t iic, len_t jjc, int ifd, int nstncl, int jpn, int irelax)
+{
+	(void)soc; (void)irelax;
+	if (!dirichlet(jpn, "BMG2_SymStd_SETUP_interp_OI")) return;
+	size_t P = (size_t)iif * jjf, PC = (size_t)iic * jjc;
+	Staged sso(so, P * nstncl, true, false), sci(ci, PC * 8, true, true);
+	setup_interp2(sso.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, current_stream());
+}
+
+void BMG2_SymStd_SETUP_ITLI_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf,
+                               len_t iic, len_t jjc, int ifd, int nstncl, int ipn)
+{
+	if (!dirichlet(ipn, "BMG2_SymStd_SETUP_ITLI_ex")) return;
+	size_t P = (size_t)iif * jjf, PC = (size_t)iic * jjc;
+	Staged sso(so, P * nstncl, true, false), ssoc(soc, PC * 5, true, true), sci(ci, PC * 8, true, false);
+	galerkin2(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, current_stream());
+}
+
+static void cg_info(int *dinfo, const char *who)
+{
+	int info = 0;
+	cedar_amd_memcpy_d2h(&info, dinfo, sizeof(int));
+	if (info != 0) report(who);
+}
+
+void BMG2_SymStd_SETUP_cg_LU(real_t *so, len_t *ii, len_t *jj, int *nstncl, real_t *abd,
+                             len_t *nabd1, len_t *nabd2, int *ibc)
+{
+	if (!dirichlet(*ibc, "BMG2_SymStd_SETUP_cg_LU")) return;
+	size_t P = (size_t)(*ii) * (*jj), NA = (size_t)(*nabd1) * (*nabd2);
+	Staged sso(so, P * (*nstncl), true, false), sabd(abd, NA, true, true);
+	int *dinfo = static_cast<int *>(pool_get(64));
+	setup_cg2(sso.get(), (int)*ii, (int)*jj, *nstncl, sabd.get(), (int)*nabd1, (int)*nabd2, dinfo, current_stream());
+	cg_info(dinfo, "Coarse grid Cholesky decomp failed!");
+	pool_put(dinfo, 64);
+}
+
+void BMG2_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, real_t *abd, real_t *bbd,
+                          len_t nabd1, len_t nabd2, int ibc)
+{
+	if (!dirichlet(ibc, "BMG2_SymStd_SOLVE_cg")) return;
+	size_t P = (size_t)ii * jj, NA = (size_t)nabd1 * nabd2;
+	Staged sq(q, P, true, true), sqf(qf, P, true, false), sabd(abd, NA, true, false), sb(bbd, nabd2, false, true);
+	solve_cg2(sq.get(), sqf.get(), (int)ii, (int)jj, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
+}
+
+// ------------------------------------------------------------------ 3D drop-ins
+void BMG3_SymStd_SETUP_recip(real_t *so, real_t *sor, len_t nx, len_t ny, len_t nz, int nstencl, int nsorv)
+{
+	(void)nsorv;
+	size_t P = (size_t)nx * ny * nz;
+	Staged sso(so, P * nstencl, true, false), ssor(sor, P * 2, true, true);
+	setup_recip(sso.get() + KP * P, ssor.get() + P, nx, ny, nz, current_stream());
+}
+
+void BMG3_SymStd_relax_GS(int kg, real_t *so, real_t *qf, real_t *q, real_t *sor,
+                          len_t ii, len_t jj, len_t kk, int ifd, int nstncl, int nsorv,
+                          int irelax_sym, int updown, int jpn)
+{
+	(void)kg; (void)nsorv;
+	if (!dirichlet(jpn, "BMG3_SymStd_relax_GS")) return;
+	size_t P = (size_t)ii * jj * kk;
+	int nst_eff = (ifd != 1) ? 14 : 4;
+	if (nst_eff > nstncl) nst_eff = nstncl;
+	// NONSYM always sweeps in the UP order in 3D (relax_GS.f90:85-94)
+	int ud = (irelax_sym == 0) ? BMG_UP : updown;
+	Staged sso(so, P * nstncl, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, nst_eff, ud, current_stream());
+}
+
+void BMG3_SymStd_residual(int kg, int NOG, int ifd, real_t *q, real_t *qf, real_t *so, real_t *RES,
+                          len_t ii, len_t jj, len_t kk, int NStncl)
+{
+	size_t P = (size_t)ii * jj * kk;
+	int nst_eff = (kg < NOG || ifd != 1) ? 14 : 4; // residual.f90:67
+	if (nst_eff > NStncl) nst_eff = NStncl;
+	Staged sso(so, P * NStncl, true, false), sqf(qf, P, true, false), sq(q, P, true, false), sr(RES, P, true, true);
+	residual3(sso.get(), sqf.get(), sq.get(), sr.get(), (int)ii, (int)jj, (int)kk, nst_eff, current_stream());
+}
+
+void BMG3_SymStd_restrict(real_t *q, real_t *qc, real_t *ci, len_t nx, len_t ny, len_t nz,
+                          len_t nxc, len_t nyc, len_t nzc, int jpn)
+{
+	if (!dirichlet(jpn, "BMG3_SymStd_restrict")) return;
+	size_t P = (size_t)nx * ny * nz, PC = (size_t)nxc * nyc * nzc;
+	Staged sq(q, P, true, false), sqc(qc, PC, true, true), sci(ci, PC * 26, true, false);
+	restrict3(sq.get(), sqc.get(), sci.get(), (int)nx, (int)ny, (int)nz, (int)nxc, (int)nyc, (int)nzc, current_stream());
+}
+
+void BMG3_SymStd_interp_add(real_t *q, real_t *qc, real_t *so, real_t *res, real_t *ci,
+                            len_t iic, len_t jjc, len_t kkc, len_t iif, len_t jjf, len_t kkf,
+                            int NStncl, int jpn)
+{
+	if (!dirichlet(jpn, "BMG3_SymStd_interp_add")) return;
+	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
+	Staged sq(q, P, true, true), sqc(qc, PC, true, false), sso(so, P * NStncl, true, false),
+	    sr(res, P, true, true), sci(ci, PC * 26, true, false);
+	interp_add3(sq.get(), sqc.get(), sso.get(), sr.get(), sci.get(), (int)iic, (int)jjc, (int)kkc,
+	            (int)iif, (int)jjf, (int)kkf, current_stream());
+}
+
+void BMG3_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                 len_t iic, len_t jjc, len_t kkc, int ifd, int nstncl, int irelax,
+                                 int jpn, real_t *yo)
+{
+	(void)soc; (void)irelax; (void)yo;
+	if (!dirichlet(jpn, "BMG3_SymStd_SETUP_interp_OI")) return;
+	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
+	Staged sso(so, P * nstncl, true, false), sci(ci, PC * 26, true, true);
+	setup_interp3(sso.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc, ifd, current_stream());
+}
+
+static void itli3(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                  len_t iic, len_t jjc, len_t kkc, int ipn, int nst)
+{
+	if (!dirichlet(ipn, "BMG3_SymStd_SETUP_ITLI_ex")) return;
+	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
+	Staged sso(so, P * nst, true, false), ssoc(soc, PC * 14, true, true), sci(ci, PC * 26, true, false);
+	galerkin3(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc,
+	          nst == 4, current_stream());
+}
+
+void BMG3_SymStd_SETUP_ITLI07_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                 len_t iic, len_t jjc, len_t kkc, int ipn)
+{
+	itli3(so, soc, ci, iif, jjf, kkf, iic, jjc, kkc, ipn, 4);
+}
+
+void BMG3_SymStd_SETUP_ITLI27_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                 len_t iic, len_t jjc, len_t kkc, int ipn)
+{
+	itli3(so, soc, ci, iif, jjf, kkf, iic, jjc, kkc, ipn, 14);
+}
+
+void BMG3_SymStd_SETUP_cg_LU(real_t *so, len_t ii, len_t jj, len_t kk, int NStncl, real_t *abd,
+                             len_t nabd1, len_t nabd2, int ibc)
+{
+	if (!dirichlet(ibc, "BMG3_SymStd_SETUP_cg_LU")) return;
+	if (NStncl != 14 && NStncl != 4) {
+		report("Cholesky decomp failed! (incorrect NStncl)");
+		return;
+	}
+	size_t P = (size_t)ii * jj * kk, NA = (size_t)nabd1 * nabd2;
+	Staged sso(so, P * NStncl, true, false), sabd(abd, NA, true, true);
+	int *dinfo = static_cast<int *>(pool_get(64));
+	setup_cg3(sso.get(), (int)ii, (int)jj, (int)kk, NStncl, sabd.get(), (int)nabd1, (int)nabd2, dinfo, current_stream());
+	cg_info(dinfo, "Coarse grid Cholesky decomp failed!");
+	pool_put(dinfo, 64);
+}
+
+void BMG3_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, len_t kk, real_t *abd,
+                          real_t *bbd, len_t nabd1, len_t nabd2, int ibc)
+{
+	if (!dirichlet(ibc, "BMG3_SymStd_SOLVE_cg")) return;
+	size_t P = (size_t)ii * jj * kk, NA = (size_t)nabd1 * nabd2;
+	Staged sq(q, P, true, true), sqf(qf, P, true, false), sabd(abd, NA, true, false), sb(bbd, nabd2, false, true);
+	solve_cg3(sq.get(), sqf.get(), (int)ii, (int)jj, (int)kk, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
+}
+
+} // extern "C"

@@ -1,0 +1,106 @@
+// cedar_amd -- MI355X-native BoxMG V-cycle hot path.
+// Shared declarations for the HIP kernels (gfx950 only) and the C-ABI.
+//
+// Data layout (identical to the reference so that the drop-in boundary needs
+// no conversion): FP64, Fortran order (first index fastest), one ghost layer on
+// every side, II = nx+2 ...; stencil operators are SoA "planes", slot s at
+// offset s*II*JJ[*KK] (include/cedar/array.h:67-74, stencil_op_nd.h:41-78 of
+// the reference).  All device code is compiled with -ffp-contract=off and keeps
+// the reference's term order, so the solve-phase kernels round exactly like
+// the reference's FMA-free CPU build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+namespace cedar_amd {
+
+typedef double real_t;
+typedef unsigned int len_t;
+
+enum { BMG_DOWN = 0, BMG_UP = 1 };
+// 2D slots (src/2d/ftn/BMG_stencils_f90.h:29-37, 0-based)
+enum { KO = 0, KW = 1, KS = 2, KSW = 3, KNW = 4 };
+enum { LL = 0, LR = 1, LA = 2, LB = 3, LSW = 4, LNW = 5, LNE = 6, LSE = 7 };
+// 3D slots (:43-64)
+enum { KP = 0, KPW = 1, KPS = 2, KB = 3, KPSW = 4, KPNW = 5, KBW = 6, KBNW = 7,
+       KBN = 8, KBNE = 9, KBE = 10, KBSE = 11, KBS = 12, KBSW = 13 };
+enum { LXYL = 0, LXYR = 1, LXYA = 2, LXYB = 3, LXZA = 4, LXZB = 5,
+       LXYNE = 6, LXYSE = 7, LXYSW = 8, LXYNW = 9, LXZSW = 10, LXZNW = 11,
+       LXZNE = 12, LXZSE = 13, LYZSW = 14, LYZNW = 15, LYZNE = 16, LYZSE = 17,
+       LBSW = 18, LBNW = 19, LBNE = 20, LBSE = 21,
+       LTSW = 22, LTNW = 23, LTNE = 24, LTSE = 25 };
+
+#define CEDAR_HIP_CHECK(expr)                                                         \
+	do {                                                                              \
+		hipError_t e_ = (expr);                                                       \
+		if (e_ != hipSuccess) {                                                       \
+			fprintf(stderr, "[cedar_amd] HIP error %s at %s:%d: %s\n",                \
+			        hipGetErrorName(e_), __FILE__, __LINE__, hipGetErrorString(e_)); \
+			abort();                                                                  \
+		}                                                                             \
+	} while (0)
+
+// 8-byte-aligned pair of doubles: rows start at arbitrary parity, the hardware
+// handles the unaligned dwordx4.
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// ---- kernel launchers (device pointers, asynchronous on `st`) ----
+// relax3d.hip
+void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, size_t KK, hipStream_t st);
+void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+               int II, int JJ, int KK, int nstncl, int updown, hipStream_t st);
+// relax2d.hip
+void relax2_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+               int II, int JJ, int nstncl, int updown, hipStream_t st);
+// residual.hip
+void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
+               int II, int JJ, int nstncl, hipStream_t st);
+void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
+               int II, int JJ, int KK, int nstncl, hipStream_t st);
+// sum of squares over the interior -> *out (deterministic two-stage tree); scratch >= 4096 doubles
+void sumsq_interior(const real_t *v, int II, int JJ, int KK, real_t *scratch, real_t *out, hipStream_t st);
+// transfer.hip
+void restrict2(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int IIC, int JJC, hipStream_t st);
+void restrict3(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int KK,
+               int IIC, int JJC, int KKC, hipStream_t st);
+void interp_add2(real_t *q, const real_t *qc, real_t *res, const real_t *so, const real_t *ci,
+                 int IIC, int JJC, int IIF, int JJF, hipStream_t st);
+void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, const real_t *ci,
+                 int IIC, int JJC, int KKC, int IIF, int JJF, int KKF, hipStream_t st);
+// setup_interp.hip
+void setup_interp2(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, hipStream_t st);
+void setup_interp3(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,
+                   int IIC, int JJC, int KKC, int ifd, hipStream_t st);
+// galerkin.hip
+void galerkin2(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int IIC, int JJC,
+               int ifd, hipStream_t st);
+void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
+               int IIC, int JJC, int KKC, int ifd, hipStream_t st);
+// lines.hip
+void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st);
+void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st);
+void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int nstncl, int updown, hipStream_t st);
+void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int nstncl, int updown, hipStream_t st);
+// cgsolve.hip
+void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
+void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);
+void setup_cg3(const real_t *so, int II, int JJ, int KK, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
+void solve_cg3(real_t *q, const real_t *qf, int II, int JJ, int KK, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);
+// gallery.hip (device-side generators of the reference's gallery operators)
+void gallery_fill(int which, real_t *so, real_t *b, int nx, int ny, int nz, const double *params, hipStream_t st);
+
+// XCD-aware block remap: consecutive logical blocks land on the same XCD
+// (blocks b and b+8 share an XCD under round-robin dispatch; speed only).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
+{
+	unsigned chunk = (nblk + 7u) >> 3;
+	return (b & 7u) * chunk + (b >> 3);
+}
+static inline unsigned xcd_grid(unsigned nblk) { return ((nblk + 7u) >> 3) << 3; }
+
+} // namespace cedar_amd

@@ -1,0 +1,344 @@
+// 3D point relaxation: 27-point 8-colour and 7-point red-black Gauss-Seidel.
+// Replaces BMG3_SymStd_relax_GS / BMG3_SymStd_SETUP_recip
+// (reference src/3d/ftn/BMG3_SymStd_relax_GS.f90:80-187, SETUP_recip.f90:63-69).
+//
+// 27-point design (HBM-bound, 136 algorithmic B/DOF):
+//   The eight colours are (i,j,k) parities swept in the order i fastest.  Two
+//   consecutive colours differ only in i-parity and couple only through
+//   i+-1 neighbours *of the same grid row*, so one workgroup that owns a whole
+//   row (j,k) can relax colour 2c+1 and then colour 2c+2 of that row without
+//   any other workgroup's data: 4 launches per sweep instead of 8, every row
+//   stream is read with unit stride (no stride-2 half-line waste), and the
+//   row is written once.  Each lane owns the adjacent pair (i_e, i_o) =
+//   (2p+2, 2p+3); the freshly relaxed first-colour values travel to the
+//   neighbouring lane through a 4 KB LDS row.
+//   Rows are dealt to XCDs in contiguous k-slabs so that the q rows shared by
+//   neighbouring workgroups (j+-1, k+-1) are re-read from that XCD's L2.
+//
+// Arithmetic: the 26 products are added in the reference's order and the file
+// is compiled with -ffp-contract=off: results are bit-identical to the
+// reference's CPU build.
+#include "common.h"
+
+namespace cedar_amd {
+
+// ------------------------------------------------------------------ recip
+__global__ void recip_kernel(const real_t *__restrict__ d, real_t *__restrict__ r,
+                             int II, int JJ, int KK)
+{
+	size_t n = (size_t)II * JJ * KK;
+	for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n;
+	     idx += (size_t)gridDim.x * blockDim.x) {
+		int i = (int)(idx % II);
+		size_t t = idx / II;
+		int j = (int)(t % JJ);
+		int k = (int)(t / JJ);
+		bool in = i >= 1 && i <= II - 2 && j >= 1 && j <= JJ - 2 && (KK == 1 || (k >= 1 && k <= KK - 2));
+		if (in) r[idx] = 1.0 / d[idx];
+	}
+}
+
+void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, size_t KK, hipStream_t st)
+{
+	size_t n = II * JJ * KK;
+	unsigned grid = (unsigned)((n + 255) / 256);
+	if (grid > 8192) grid = 8192;
+	hipLaunchKernelGGL(recip_kernel, dim3(grid), dim3(256), 0, st, so_diag, sor_msor, (int)II, (int)JJ, (int)KK);
+}
+
+// ------------------------------------------------------------------ 27-pt
+// coefficients seen from one grid point X=(i,j,k); names = slot _ where stored
+struct C27 {
+	real_t pw, ps, psw, b, bw, bs, bsw;       // stored at X
+	real_t pnw_n, ps_n, bnw_n, bn_n;          // stored at X+(0,1,0)
+	real_t b_t, be_t, bn_t, bne_t;            // stored at X+(0,0,1)
+	real_t bse_nt, bs_nt;                     // stored at X+(0,1,1)
+	real_t psw_ne, bne_ne;                    // stored at X+(1,1,0)
+	real_t pw_e, pnw_e, be_e, bse_e;          // stored at X+(1,0,0)
+	real_t bsw_net;                           // stored at X+(1,1,1)
+	real_t bw_et, bnw_et;                     // stored at X+(1,0,1)
+};
+
+// qq[dk+1][dj+1][di+1]; term order of BMG3_SymStd_relax_GS.f90:104-131
+__device__ __forceinline__ real_t offdiag27(real_t qf, const C27 &c, const real_t (&qq)[3][3][3])
+{
+	real_t s = qf;
+	s = s + c.pw * qq[1][1][0];
+	s = s + c.pnw_n * qq[1][2][0];
+	s = s + c.ps_n * qq[1][2][1];
+	s = s + c.psw_ne * qq[1][2][2];
+	s = s + c.pw_e * qq[1][1][2];
+	s = s + c.pnw_e * qq[1][0][2];
+	s = s + c.ps * qq[1][0][1];
+	s = s + c.psw * qq[1][0][0];
+	s = s + c.b * qq[0][1][1];
+	s = s + c.bw * qq[0][1][0];
+	s = s + c.bnw_n * qq[0][2][0];
+	s = s + c.bn_n * qq[0][2][1];
+	s = s + c.bne_ne * qq[0][2][2];
+	s = s + c.be_e * qq[0][1][2];
+	s = s + c.bse_e * qq[0][0][2];
+	s = s + c.bs * qq[0][0][1];
+	s = s + c.bsw * qq[0][0][0];
+	s = s + c.b_t * qq[2][1][1];
+	s = s + c.be_t * qq[2][1][0];
+	s = s + c.bse_nt * qq[2][2][0];
+	s = s + c.bs_nt * qq[2][2][1];
+	s = s + c.bsw_net * qq[2][2][2];
+	s = s + c.bw_et * qq[2][1][2];
+	s = s + c.bnw_et * qq[2][0][2];
+	s = s + c.bn_t * qq[2][0][1];
+	s = s + c.bne_t * qq[2][0][0];
+	return s;
+}
+
+// direct-from-memory evaluation at one point (generic path; i,j,k 0-based incl. ghost)
+__device__ __forceinline__ real_t offdiag27_mem(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                const real_t *__restrict__ q, size_t II, size_t JJ, size_t PS,
+                                                size_t x)
+{
+	const size_t sj = II, sk = II * JJ;
+	C27 c;
+	c.pw = so[KPW * PS + x]; c.ps = so[KPS * PS + x]; c.psw = so[KPSW * PS + x];
+	c.b = so[KB * PS + x]; c.bw = so[KBW * PS + x]; c.bs = so[KBS * PS + x]; c.bsw = so[KBSW * PS + x];
+	c.pnw_n = so[KPNW * PS + x + sj]; c.ps_n = so[KPS * PS + x + sj];
+	c.bnw_n = so[KBNW * PS + x + sj]; c.bn_n = so[KBN * PS + x + sj];
+	c.b_t = so[KB * PS + x + sk]; c.be_t = so[KBE * PS + x + sk];
+	c.bn_t = so[KBN * PS + x + sk]; c.bne_t = so[KBNE * PS + x + sk];
+	c.bse_nt = so[KBSE * PS + x + sj + sk]; c.bs_nt = so[KBS * PS + x + sj + sk];
+	c.psw_ne = so[KPSW * PS + x + 1 + sj]; c.bne_ne = so[KBNE * PS + x + 1 + sj];
+	c.pw_e = so[KPW * PS + x + 1]; c.pnw_e = so[KPNW * PS + x + 1];
+	c.be_e = so[KBE * PS + x + 1]; c.bse_e = so[KBSE * PS + x + 1];
+	c.bsw_net = so[KBSW * PS + x + 1 + sj + sk];
+	c.bw_et = so[KBW * PS + x + 1 + sk]; c.bnw_et = so[KBNW * PS + x + 1 + sk];
+	real_t qq[3][3][3];
+#pragma unroll
+	for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+		for (int dj = 0; dj < 3; dj++)
+#pragma unroll
+			for (int di = 0; di < 3; di++)
+				qq[dk][dj][di] = q[x + (di - 1) + (ptrdiff_t)(dj - 1) * (ptrdiff_t)sj + (ptrdiff_t)(dk - 1) * (ptrdiff_t)sk];
+	return offdiag27(qf[x], c, qq);
+}
+
+// generic fallback: one colour per launch, one thread per colour point
+__global__ void relax27_colour(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                               real_t *__restrict__ q, const real_t *__restrict__ sor,
+                               int II, int JJ, int KK, int ib, int jb, int kb)
+{
+	int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	size_t n = (size_t)ni * nj * nk;
+	size_t PS = (size_t)II * JJ * KK;
+	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+		int a = (int)(t % ni);
+		size_t r = t / ni;
+		int b = (int)(r % nj), c = (int)(r / nj);
+		size_t x = (size_t)(1 + ib + 2 * a) + (size_t)II * ((size_t)(1 + jb + 2 * b) + (size_t)JJ * (size_t)(1 + kb + 2 * c));
+		q[x] = offdiag27_mem(so, qf, q, II, JJ, PS, x) * sor[PS + x];
+	}
+}
+
+// load the pair (ptr[0], ptr[1]); `two` false -> only ptr[0] is inside the row
+__device__ __forceinline__ void ldpair(const real_t *__restrict__ p, bool two, real_t &a, real_t &b)
+{
+	if (two) {
+		d2u v = *reinterpret_cast<const d2u *>(p);
+		a = v.x; b = v.y;
+	} else {
+		a = p[0]; b = 0.0;
+	}
+}
+
+// fast path: one workgroup = one grid row, both i-colours.
+//   EFIRST = true : colour with even 1-based i (i = 2,4,..) first  (UP order)
+//   EFIRST = false: odd i first                                     (DOWN order)
+template <int BS, bool EFIRST>
+__global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                    real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                    int II, int JJ, int KK, int jb, int kb, int nrj, int nrk)
+{
+	__shared__ real_t xch[BS + 2];
+	const unsigned nblk = (unsigned)nrj * (unsigned)nrk;
+	const unsigned L = xcd_remap(blockIdx.x, nblk);
+	if (L >= nblk) return; // whole workgroup leaves together
+	const int jr = (int)(L % (unsigned)nrj), kr = (int)(L / (unsigned)nrj);
+	const size_t j = (size_t)(1 + jb + 2 * jr), k = (size_t)(1 + kb + 2 * kr); // 0-based incl. ghost
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
+	const size_t row = j * sj + k * sk;
+
+	const int p = threadIdx.x;
+	const int ie = 2 * p + 1, io = 2 * p + 2;     // 0-based offsets of the pair in the row
+	const bool e_ok = ie <= II - 2;                // interior?
+	const bool o_ok = io <= II - 2;
+	const bool two = io + 1 <= II - 1;             // element io+1 still inside the row
+
+	real_t e_new = 0.0, o_new = 0.0;
+	C27 ce, co;
+	real_t qe[3][3][3], qo[3][3][3];
+	real_t qfe = 0, qfo = 0, sre = 0, sro = 0;
+
+	if (e_ok) {
+		// ---- [i]-pattern streams: (value at ie, value at io)
+#define LD_I(slot, off, fe, fo)                                                        \
+	{                                                                                  \
+		real_t a_, b_;                                                                 \
+		ldpair(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);               \
+		ce.fe = a_; co.fo = b_;                                                        \
+	}
+		LD_I(KPW, 0, pw, pw) LD_I(KPS, 0, ps, ps) LD_I(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
+		LD_I(KBW, 0, bw, bw) LD_I(KBS, 0, bs, bs) LD_I(KBSW, 0, bsw, bsw)
+		LD_I(KPNW, sj, pnw_n, pnw_n) LD_I(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
+		LD_I(KB, sk, b_t, b_t) LD_I(KBE, sk, be_t, be_t) LD_I(KBN, sk, bn_t, bn_t) LD_I(KBNE, sk, bne_t, bne_t)
+		LD_I(KBSE, sj + sk, bse_nt, bse_nt) LD_I(KBS, sj + sk, bs_nt, bs_nt)
+#undef LD_I
+		// ---- [i+1]-pattern streams: (value at ie+1 = io, value at io+1)
+#define LD_IP(slot, off, f)                                                            \
+	{                                                                                  \
+		real_t a_, b_;                                                                 \
+		ldpair(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);                \
+		ce.f = a_; co.f = b_;                                                          \
+	}
+		LD_IP(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
+		LD_IP(KPW, 0, pw_e) LD_IP(KPNW, 0, pnw_e) LD_IP(KBE, 0, be_e) LD_IP(KBSE, 0, bse_e)
+		LD_IP(KBSW, sj + sk, bsw_net)
+		LD_IP(KBW, sk, bw_et) LD_IP(KBNW, sk, bnw_et)
+#undef LD_IP
+		{
+			real_t a_, b_;
+			ldpair(qf + row + ie, true, a_, b_); qfe = a_; qfo = b_;
+			ldpair(sor + PS + row + ie, true, a_, b_); sre = a_; sro = b_;
+		}
+		// ---- q windows: offsets ie-1 .. io+1 of the nine rows
+#pragma unroll
+		for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+			for (int dj = 0; dj < 3; dj++) {
+				const real_t *r = q + row + (ptrdiff_t)(dj - 1) * (ptrdiff_t)sj + (ptrdiff_t)(dk - 1) * (ptrdiff_t)sk;
+				real_t w0, w1, w2, w3;
+				ldpair(r + ie - 1, true, w0, w1);
+				ldpair(r + io, two, w2, w3);
+				qe[dk][dj][0] = w0; qe[dk][dj][1] = w1; qe[dk][dj][2] = w2;
+				qo[dk][dj][0] = w1; qo[dk][dj][1] = w2; qo[dk][dj][2] = w3;
+			}
+	}
+
+	if (EFIRST) {
+		if (e_ok) {
+			e_new = offdiag27(qfe, ce, qe) * sre;
+			xch[p] = e_new;
+		}
+		__syncthreads();
+		if (o_ok) {
+			qo[1][1][0] = e_new;
+			if (io + 1 <= II - 2) qo[1][1][2] = xch[p + 1]; // next pair's fresh e (else ghost: old value)
+			o_new = offdiag27(qfo, co, qo) * sro;
+		}
+	} else {
+		if (o_ok) {
+			o_new = offdiag27(qfo, co, qo) * sro;
+			xch[p + 1] = o_new;
+		}
+		__syncthreads();
+		if (e_ok) {
+			if (p > 0) qe[1][1][0] = xch[p]; // previous pair's fresh o (p == 0: ghost column)
+			if (o_ok) qe[1][1][2] = o_new;
+			e_new = offdiag27(qfe, ce, qe) * sre;
+		}
+	}
+	if (e_ok) {
+		if (o_ok) {
+			d2u v; v.x = e_new; v.y = o_new;
+			*reinterpret_cast<d2u *>(q + row + ie) = v;
+		} else {
+			q[row + ie] = e_new;
+		}
+	}
+}
+
+// ------------------------------------------------------------------ 7-pt
+// src/3d/ftn/BMG3_SymStd_relax_GS.f90:155-184: colour = mod(i+j+k+pts,2) in 1-based indices
+__global__ void relax7_colour(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                              real_t *__restrict__ q, const real_t *__restrict__ sor,
+                              int II, int JJ, int KK, int pts)
+{
+	const int nxh = (II - 2 + 1) / 2; // max points of one colour in a row
+	size_t n = (size_t)nxh * (JJ - 2) * (KK - 2);
+	const size_t sj = II, sk = (size_t)II * JJ, PS = sk * KK;
+	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+		int a = (int)(t % nxh);
+		size_t r = t / nxh;
+		int j1 = 2 + (int)(r % (JJ - 2)), k1 = 2 + (int)(r / (JJ - 2)); // 1-based
+		int i1 = (j1 + k1 + pts) % 2 + 2 + 2 * a;
+		if (i1 > II - 1) continue;
+		size_t x = (size_t)(i1 - 1) + sj * (size_t)(j1 - 1) + sk * (size_t)(k1 - 1);
+		real_t s = qf[x];
+		s = s + so[KPW * PS + x] * q[x - 1];
+		s = s + so[KPS * PS + x + sj] * q[x + sj];
+		s = s + so[KPW * PS + x + 1] * q[x + 1];
+		s = s + so[KPS * PS + x] * q[x - sj];
+		s = s + so[KB * PS + x] * q[x - sk];
+		s = s + so[KB * PS + x + sk] * q[x + sk];
+		q[x] = s * sor[PS + x];
+	}
+}
+
+static inline unsigned cap_grid(size_t n, unsigned bs)
+{
+	size_t g = (n + bs - 1) / bs;
+	if (g > 16384) g = 16384;
+	if (g < 1) g = 1;
+	return (unsigned)g;
+}
+
+template <int BS>
+static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                        int II, int JJ, int KK, int jb, int kb, hipStream_t st)
+{
+	int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	if (nrj <= 0 || nrk <= 0) return;
+	unsigned grid = xcd_grid((unsigned)nrj * (unsigned)nrk);
+	if (efirst)
+		hipLaunchKernelGGL((relax27_rows<BS, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk);
+	else
+		hipLaunchKernelGGL((relax27_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk);
+}
+
+void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+               int II, int JJ, int KK, int nstncl, int updown, hipStream_t st)
+{
+	if (II < 3 || JJ < 3 || KK < 3) return;
+	if (nstncl == 14) {
+		const bool up = (updown == BMG_UP);
+		const int npairs = (II - 2 + 1) / 2;
+		if (npairs <= 512) {
+			// colour pairs in sweep order: UP (j,k) parities 00,10,01,11 with even-i first
+			for (int c = 0; c < 4; c++) {
+				int cc = up ? c : 3 - c;
+				int jb = cc & 1, kb = cc >> 1;
+				if (npairs <= 64) launch_rows<64>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+				else if (npairs <= 128) launch_rows<128>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+				else if (npairs <= 256) launch_rows<256>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+				else launch_rows<512>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+			}
+		} else {
+			for (int c = 0; c < 8; c++) {
+				int pts = up ? c : 7 - c;
+				int ib = pts & 1, jb = (pts >> 1) & 1, kb = (pts >> 2) & 1;
+				int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+				if (ni <= 0 || nj <= 0 || nk <= 0) continue;
+				hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nk, 256)), dim3(256), 0, st,
+				                   so, qf, q, sor, II, JJ, KK, ib, jb, kb);
+			}
+		}
+	} else {
+		// 7-point: UP = colours 0,1; DOWN = 1,0 (:144-153)
+		for (int c = 0; c < 2; c++) {
+			int pts = (updown == BMG_UP) ? c : 1 - c;
+			size_t n = (size_t)((II - 2 + 1) / 2) * (JJ - 2) * (KK - 2);
+			hipLaunchKernelGGL(relax7_colour, dim3(cap_grid(n, 256)), dim3(256), 0, st, so, qf, q, sor, II, JJ, KK, pts);
+		}
+	}
+}
+
+} // namespace cedar_amd

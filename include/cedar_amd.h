@@ -1,0 +1,181 @@
+/* cedar_amd -- C ABI of the MI355X-native BoxMG V-cycle hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ * 1. Kernel drop-ins.  Exactly the `extern "C"` symbols that Cedar's C++
+ *    binding classes call into its Fortran library;
+ *    same names, argument order, by-value/by-pointer conventions and array
+ *    layouts (FP64, Fortran order, one ghost layer, pointer to the first
+ *    element including ghosts).  Each array argument may be a host pointer
+ *    (the library stages it through HBM: correct, PCIe-bound) or a device
+ *    pointer obtained from cedar_amd_malloc/hipMalloc (operated on in place).
+ *    Linking Cedar against libcedar_amd.so instead of its Fortran objects
+ *    therefore routes the whole hot path to the GPU without source changes.
+ *    Only Dirichlet boundaries (per_mask = 0, ibc = BMG_BCs_definite) are
+ *    implemented; other values report through print_error and return.
+ *
+ * 2. Handle API.  Device-resident hierarchy, modelled on Cedar's own C
+ *    interface (include/cedar/2d/interface/c/solver.h: bmg2_solver_create /
+ *    _run / _destroy): create uploads the fine operator and runs the whole
+ *    set-up phase on the GPU, run/vcycle keep every level in HBM.
+ *
+ * Errors: like the reference, kernels report through the host-supplied
+ * callback `print_error(char*)` (src/2d/ftn/ModInterface.f90:4-9); if the
+ * host program does not define it the library's weak default writes to stderr.
+ * Threading: none (one solver per process/rank, like the reference).
+ */
+#ifndef CEDAR_AMD_H
+#define CEDAR_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double real_t;
+typedef unsigned int len_t;
+
+/* ------------------------------------------------------------------ 1. drop-ins */
+
+/* replaces src/2d/ftn/BMG_get_bc.f90:1-24 (decl. include/cedar/2d/relax.h:24) */
+void BMG_get_bc(int per_mask, int *ibc);
+
+/* include/cedar/2d/relax.h:13  <- src/2d/ftn/BMG2_SymStd_SETUP_recip.f90 */
+void BMG2_SymStd_SETUP_recip(real_t *so, real_t *sor, len_t nx, len_t ny, int nstncl, int nsor_v);
+/* include/cedar/2d/relax.h:14-15 <- BMG2_SymStd_SETUP_lines_x/_y.f90 */
+void BMG2_SymStd_SETUP_lines_x(real_t *SO, real_t *SOR, len_t Nx, len_t Ny, int NStncl, int JPN);
+void BMG2_SymStd_SETUP_lines_y(real_t *SO, real_t *SOR, len_t Nx, len_t Ny, int NStncl, int JPN);
+/* include/cedar/2d/relax.h:16-17 <- BMG2_SymStd_relax_GS.f90 */
+void BMG2_SymStd_relax_GS(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, len_t II, len_t JJ,
+                          int kf, int ifd, int nstncl, int nsorv, int irelax_sym, int updown, int jpn);
+/* include/cedar/2d/relax.h:18-23 <- BMG2_SymStd_relax_lines_x/_y.f90 */
+void BMG2_SymStd_relax_lines_x(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, real_t *B,
+                               len_t II, len_t JJ, int kf, int ifd, int nstencil, int irelax_sym,
+                               int updown, int jpn);
+void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, real_t *B,
+                               len_t II, len_t JJ, int kf, int ifd, int nstencil, int irelax_sym,
+                               int updown, int jpn);
+/* include/cedar/2d/residual.h:9-10 <- BMG2_SymStd_residual.f90 (everything by pointer) */
+void BMG2_SymStd_residual(int *k, real_t *SO, real_t *QF, real_t *Q, real_t *RES, len_t *II, len_t *JJ,
+                          int *kf, int *ifd, int *nstncl, int *ibc, int *irelax, int *irelax_sym,
+                          int *updown);
+/* src/2d/restrict.cc:6-7 <- BMG2_SymStd_restrict.f90 */
+void BMG2_SymStd_restrict(real_t *Q, real_t *QC, real_t *CI, int Nx, int Ny, int Nxc, int Nyc, int jpn);
+/* src/2d/interp.cc:8-9 <- BMG2_SymStd_interp_add.f90 */
+void BMG2_SymStd_interp_add(real_t *Q, real_t *QC, real_t *RES, real_t *SO, real_t *CI,
+                            len_t IIC, len_t JJC, len_t IIF, len_t JJF, int nstncl, int jpn);
+/* src/2d/interp.cc:10-12 <- BMG2_SymStd_SETUP_interp_OI.f90 */
+void BMG2_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf,
+                                 len_t iic, len_t jjc, int ifd, int nstncl, int jpn, int irelax);
+/* include/cedar/2d/coarsen.h:10-12 <- BMG2_SymStd_SETUP_ITLI_ex.f90 */
+void BMG2_SymStd_SETUP_ITLI_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf,
+                               len_t iic, len_t jjc, int ifd, int nstncl, int ipn);
+/* include/cedar/2d/solve_cg.h:10 <- BMG2_SymStd_SETUP_cg_LU.f90 (everything by pointer) */
+void BMG2_SymStd_SETUP_cg_LU(real_t *so, len_t *ii, len_t *jj, int *nstncl, real_t *abd,
+                             len_t *nabd1, len_t *nabd2, int *ibc);
+/* src/2d/solve_cg.cc:6 <- BMG2_SymStd_SOLVE_cg.f90 */
+void BMG2_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, real_t *abd, real_t *bbd,
+                          len_t nabd1, len_t nabd2, int ibc);
+
+/* include/cedar/3d/relax.h:11-16 */
+void BMG3_SymStd_SETUP_recip(real_t *so, real_t *sor, len_t nx, len_t ny, len_t nz, int nstencl, int nsorv);
+void BMG3_SymStd_relax_GS(int kg, real_t *so, real_t *qf, real_t *q, real_t *sor,
+                          len_t ii, len_t jj, len_t kk, int ifd, int nstncl, int nsorv,
+                          int irelax_sym, int updown, int jpn);
+/* include/cedar/3d/residual.h:10-13 */
+void BMG3_SymStd_residual(int kg, int NOG, int ifd, real_t *q, real_t *qf, real_t *so, real_t *RES,
+                          len_t ii, len_t jj, len_t kk, int NStncl);
+/* src/3d/restrict.cc:7-10 */
+void BMG3_SymStd_restrict(real_t *q, real_t *qc, real_t *ci, len_t nx, len_t ny, len_t nz,
+                          len_t nxc, len_t nyc, len_t nzc, int jpn);
+/* src/3d/interp.cc:7-11 (NB: so,res order differs from 2D) */
+void BMG3_SymStd_interp_add(real_t *q, real_t *qc, real_t *so, real_t *res, real_t *ci,
+                            len_t iic, len_t jjc, len_t kkc, len_t iif, len_t jjf, len_t kkf,
+                            int NStncl, int jpn);
+/* include/cedar/3d/interp.h:11-15 (yo is scratch of the reference and is not touched) */
+void BMG3_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                 len_t iic, len_t jjc, len_t kkc, int ifd, int nstncl, int irelax,
+                                 int jpn, real_t *yo);
+/* include/cedar/3d/coarsen.h:12-16 */
+void BMG3_SymStd_SETUP_ITLI07_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                 len_t iic, len_t jjc, len_t kkc, int ipn);
+void BMG3_SymStd_SETUP_ITLI27_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                 len_t iic, len_t jjc, len_t kkc, int ipn);
+/* include/cedar/3d/solve_cg.h:10-11, src/3d/solve_cg.cc:6-9 */
+void BMG3_SymStd_SETUP_cg_LU(real_t *so, len_t ii, len_t jj, len_t kk, int NStncl, real_t *abd,
+                             len_t nabd1, len_t nabd2, int ibc);
+void BMG3_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, len_t kk, real_t *abd,
+                          real_t *bbd, len_t nabd1, len_t nabd2, int ibc);
+
+/* ------------------------------------------------------------------ device memory helpers */
+int cedar_amd_device_count(void);                 /* 0 when no GPU is visible (no HIP context made) */
+int cedar_amd_set_device(int dev);                /* 0 on success */
+void *cedar_amd_malloc(size_t bytes);             /* zero-filled HBM */
+void cedar_amd_free(void *dptr);
+void cedar_amd_memcpy_h2d(void *dst, const void *src, size_t bytes);
+void cedar_amd_memcpy_d2h(void *dst, const void *src, size_t bytes);
+void cedar_amd_memcpy_d2d(void *dst, const void *src, size_t bytes);
+void cedar_amd_memset(void *dst, int value, size_t bytes);
+void cedar_amd_sync(void);
+/* all launches of this library go to this stream (default: the null stream) */
+void cedar_amd_set_stream(void *hip_stream);
+void *cedar_amd_get_stream(void);
+/* ||v||_2 over the interior (grid_func::lp_norm<2>); v host or device; KK = 1 for 2D */
+double cedar_amd_l2norm(const real_t *v, len_t II, len_t JJ, len_t KK);
+
+/* device-side gallery (src/2d/gallery.cc, src/3d/gallery.cc); `so`/`b` device or host.
+ * which: 0 poisson2, 1 diag_diffusion2(dx,dy), 2 fe2, 10 poisson3, 11 diag_diffusion3, 12 fe3;
+ * b (may be NULL) receives the examples' rhs (examples/basic-2d-ser/poisson.cc:15-37). */
+void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len_t nz,
+                       const double *params);
+
+/* ------------------------------------------------------------------ 2. handle API */
+typedef struct cedar_amd_solver cedar_amd_solver;
+
+enum { CEDAR_AMD_RELAX_POINT = 0, CEDAR_AMD_RELAX_LINE_X = 1, CEDAR_AMD_RELAX_LINE_Y = 2,
+       CEDAR_AMD_RELAX_LINE_XY = 3 };
+
+typedef struct {
+	int relaxation;   /* solver.relaxation   (default point)  src/multilevel_settings.cc:15-28 */
+	int nrelax_pre;   /* solver.cycle.nrelax-pre  (2)   :38 */
+	int nrelax_post;  /* solver.cycle.nrelax-post (1)   :39 */
+	int num_levels;   /* solver.num-levels (-1 = automatic) :40 */
+	int max_iter;     /* solver.max-iter (10) :41 */
+	double tol;       /* solver.tol (1e-8) :42 */
+	int min_coarse;   /* solver.min_coarse (3) :43 */
+} cedar_amd_settings;
+
+void cedar_amd_default_settings(cedar_amd_settings *s);
+
+/* nd = 2|3; nstencil = 3|5 (2D five/nine point), 4|14 (3D seven/xxvii point).
+ * `so` (host or device) is the fine operator in Cedar's layout; it is copied
+ * unless own_device_so != 0 and so is a device pointer, in which case the
+ * solver uses it in place and the caller must keep it alive (level 0 holds a
+ * reference in the reference too, include/cedar/level.h:25,31). */
+cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil,
+                                          const real_t *so, int own_device_so,
+                                          const cedar_amd_settings *settings);
+void cedar_amd_solver_destroy(cedar_amd_solver *s);
+int cedar_amd_solver_nlevels(const cedar_amd_solver *s);
+void cedar_amd_solver_level_dims(const cedar_amd_solver *s, int lvl, len_t *nx, len_t *ny, len_t *nz);
+/* copy a level array to the host for inspection: what = "A","P","SOR0","SOR1","ABD";
+ * returns the number of doubles written (0 if absent); out may be NULL to query. */
+size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what, real_t *out);
+/* one V-cycle, cycle->run(x,b): x,b host or device */
+void cedar_amd_solver_vcycle(cedar_amd_solver *s, real_t *x, const real_t *b);
+/* multilevel::solve(b,x): rel[0] = ||r0||_2, rel[i] = ||r_i||_2/||r0||_2; returns cycles run */
+int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real_t *rel);
+/* timing helper for benchmarks: n V-cycles back to back on device-resident x,b; returns
+ * elapsed milliseconds measured with HIP events on the library's stream */
+float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n);
+/* n relax sweeps on level 0 alternating DOWN/UP (the roofline microbenchmark);
+ * returns elapsed milliseconds (HIP events on the library's stream) */
+float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n);
+
+const char *cedar_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
