@@ -232,3 +232,113 @@ class Kernels:
 
     def l2(self, v):
         return l2norm(v)
+
+
+# ---------------------------------------------------------------- handle API
+lib.cedar_amd_solver_create.restype = C.c_void_p
+lib.cedar_amd_solver_create.argtypes = [C.c_int, u, u, u, C.c_int, C.c_void_p, C.c_int, C.POINTER(Settings)]
+lib.cedar_amd_solver_destroy.argtypes = [C.c_void_p]
+lib.cedar_amd_solver_nlevels.argtypes = [C.c_void_p]
+lib.cedar_amd_solver_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(u), C.POINTER(u), C.POINTER(u)]
+lib.cedar_amd_solver_get.restype = C.c_size_t
+lib.cedar_amd_solver_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+lib.cedar_amd_solver_vcycle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+lib.cedar_amd_solver_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.cedar_amd_solver_time_vcycles.restype = C.c_float
+lib.cedar_amd_solver_time_vcycles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.cedar_amd_solver_time_relax.restype = C.c_float
+lib.cedar_amd_solver_time_relax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.cedar_amd_gallery.argtypes = [C.c_int, C.c_void_p, C.c_void_p, u, u, u, C.c_void_p]
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+GALLERY = {"poisson2": (0, 3), "diag_diffusion2": (1, 3), "fe2": (2, 5),
+           "poisson3": (10, 4), "diag_diffusion3": (11, 4), "fe3": (12, 14)}
+
+
+def gallery(name, n, params=None, with_rhs=True, device=True):
+    """build a gallery operator (+ example rhs) in HBM; returns (so, b)"""
+    which, nst = GALLERY[name]
+    n = tuple(int(v) for v in n)
+    g = tuple(v + 2 for v in n[::-1])
+    mk = DeviceArray if device else (lambda s: np.zeros(s))
+    so, b = mk((nst,) + g), (mk(g) if with_rhs else None)
+    pp = None
+    if params is not None:
+        pp = (C.c_double * len(params))(*params)
+    nx, ny = n[0], n[1]
+    nz = n[2] if len(n) == 3 else 1
+    lib.cedar_amd_gallery(which, _vp(so), _vp(b), nx, ny, nz, pp)
+    return so, b
+
+
+class Solver:
+    """cedar::cdr2::solver / cdr3::solver on the device (include/cedar_amd.h, handle API)."""
+
+    def __init__(self, so, relax="point", nrelax_pre=2, nrelax_post=1, num_levels=-1,
+                 max_iter=10, tol=1e-8, min_coarse=3, share_operator=False):
+        shp = so.shape
+        self.nd = len(shp) - 1
+        nst = shp[0]
+        nx, ny = shp[-1] - 2, shp[-2] - 2
+        nz = shp[1] - 2 if self.nd == 3 else 1
+        self.shape = tuple(shp[1:])
+        st = Settings(RELAX[relax], nrelax_pre, nrelax_post, num_levels, max_iter, tol, min_coarse)
+        self.max_iter = max_iter
+        self._so = so if share_operator else None  # keep the shared operator alive
+        self.h = lib.cedar_amd_solver_create(self.nd, nx, ny, nz, nst, _vp(so), int(share_operator), C.byref(st))
+        if not self.h:
+            raise RuntimeError("cedar_amd_solver_create failed")
+
+    def nlevels(self):
+        return lib.cedar_amd_solver_nlevels(self.h)
+
+    def dims(self, lvl):
+        a, b, c = u(), u(), u()
+        lib.cedar_amd_solver_level_dims(self.h, lvl, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def array(self, lvl, what):
+        n = lib.cedar_amd_solver_get(self.h, lvl, what.encode(), None)
+        if n == 0:
+            return None
+        out = np.empty(n)
+        lib.cedar_amd_solver_get(self.h, lvl, what.encode(), out.ctypes.data)
+        if what == "ABD":
+            return out
+        nx, ny, nz = self.dims(lvl)
+        shp = (ny + 2, nx + 2) if self.nd == 2 else (nz + 2, ny + 2, nx + 2)
+        return out.reshape((-1,) + shp)
+
+    def vcycle(self, x, b):
+        lib.cedar_amd_solver_vcycle(self.h, _vp(x), _vp(b))
+
+    def solve(self, b, x):
+        rel = np.zeros(self.max_iter + 1)
+        n = lib.cedar_amd_solver_solve(self.h, _vp(b), _vp(x), rel.ctypes.data)
+        return rel[: n + 1]
+
+    def time_vcycles(self, x, b, n):
+        return lib.cedar_amd_solver_time_vcycles(self.h, x.ptr, b.ptr, n)
+
+    def time_relax(self, x, b, n):
+        return lib.cedar_amd_solver_time_relax(self.h, x.ptr, b.ptr, n)
+
+    def close(self):
+        if self.h:
+            lib.cedar_amd_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

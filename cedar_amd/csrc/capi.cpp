@@ -239,14 +239,20 @@ void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t 
                                len_t II, len_t JJ, int kf, int ifd, int nstencil, int irelax_sym,
                                int updown, int jpn)
 {
-	(void)B; // the reference's per-line scratch; the device kernel keeps lines in registers/LDS
+	(void)B; // the reference's 2*JJ per-line scratch is too small for a whole colour: own HBM scratch
 	if (!dirichlet(jpn, "BMG2_SymStd_relax_lines_y")) return;
 	size_t P = (size_t)II * JJ;
 	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
 	if (nst_eff > nstencil) nst_eff = nstencil;
 	int ud = (irelax_sym == 0) ? BMG_DOWN : updown;
-	Staged sso(SO, P * nstencil, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
-	relax_lines_y(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+	size_t nscr = ylines_scratch_doubles((int)II, (int)JJ);
+	real_t *scr = static_cast<real_t *>(pool_get(nscr * sizeof(real_t)));
+	{
+		Staged sso(SO, P * nstencil, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
+		relax_lines_y(sso.get(), sqf.get(), sq.get(), ssor.get(), scr, (int)II, (int)JJ, nst_eff, ud, current_stream());
+	}
+	CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream()));
+	pool_put(scr, nscr * sizeof(real_t));
 }
 
 void BMG2_SymStd_restrict(real_t *Q, real_t *QC, real_t *CI, int Nx, int Ny, int Nxc, int Nyc, int jpn)

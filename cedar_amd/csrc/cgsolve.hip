@@ -1,0 +1,182 @@
+// Coarsest-grid direct solve: band Cholesky set-up and solve.
+// Replaces BMG2_SymStd_SETUP_cg_LU (src/2d/ftn/BMG2_SymStd_SETUP_cg_LU.f90:92-118, :236-258),
+// BMG2_SymStd_SOLVE_cg (src/2d/ftn/BMG2_SymStd_SOLVE_cg.f90:95-125),
+// BMG3_SymStd_SETUP_cg_LU (src/3d/ftn/BMG3_SymStd_SETUP_cg_LU.f90:111-198) and
+// BMG3_SymStd_SOLVE_cg (src/3d/ftn/BMG3_SymStd_SOLVE_cg.f90:100-150), including the
+// LAPACK they call (DPBTRF/DPBTRS, UPLO='U'; system LAPACK in the reference, not
+// vendored).  The coarsest grid holds a few dozen unknowns (16 in 2D, 64 in 3D
+// for every configuration here), far below DPBTRF's blocking threshold, so the
+// published unblocked DPBTF2 / DTBSV recurrences are restated and run by ONE
+// lane in their sequential order: latency ~10 us per V-cycle, negligible
+// against the fine-level sweeps, and it keeps the solve on the device (no PCIe
+// round trip inside the cycle).  The band is packed by the whole workgroup.
+#include "common.h"
+
+namespace cedar_amd {
+
+#define ABD(r, c) abd[(size_t)((r)-1) + (size_t)nabd1 * (size_t)((c)-1)]
+
+// DPBTF2 'U' on AB(ldab, n), bandwidth kd; returns LAPACK INFO
+__device__ int dpbtf2_upper(int n, int kd, real_t *ab, int ldab)
+{
+	const int kld = ldab - 1 > 1 ? ldab - 1 : 1;
+	for (int j = 1; j <= n; j++) {
+		real_t *dj = ab + (size_t)kd + (size_t)ldab * (size_t)(j - 1); // AB(kd+1, j)
+		real_t ajj = *dj;
+		if (ajj <= 0.0) return j;
+		ajj = sqrt(ajj);
+		*dj = ajj;
+		const int kn = kd < n - j ? kd : n - j;
+		if (kn > 0) {
+			const real_t r = 1.0 / ajj;
+			real_t *x = ab + (size_t)(kd - 1) + (size_t)ldab * (size_t)j;     // AB(kd, j+1), stride kld
+			real_t *a = ab + (size_t)kd + (size_t)ldab * (size_t)j;           // AB(kd+1, j+1), lda kld
+			for (int t = 0; t < kn; t++) x[(size_t)t * kld] = r * x[(size_t)t * kld];
+			for (int c = 0; c < kn; c++) {
+				const real_t xc = x[(size_t)c * kld];
+				if (xc != 0.0) {
+					const real_t temp = -1.0 * xc;
+					for (int rr = 0; rr <= c; rr++) a[(size_t)rr + (size_t)c * kld] += x[(size_t)rr * kld] * temp;
+				}
+			}
+		}
+	}
+	return 0;
+}
+
+// DPBTRS 'U', one right-hand side: DTBSV('U','T','N') then DTBSV('U','N','N')
+__device__ void dpbtrs_upper(int n, int kd, const real_t *ab, int ldab, real_t *b)
+{
+	const int kp1 = kd + 1;
+	for (int j = 1; j <= n; j++) {
+		real_t temp = b[j - 1];
+		const int l = kp1 - j;
+		const int i0 = j - kd > 1 ? j - kd : 1;
+		for (int i = i0; i <= j - 1; i++) temp = temp - ab[(size_t)(l + i - 1) + (size_t)ldab * (size_t)(j - 1)] * b[i - 1];
+		temp = temp / ab[(size_t)kd + (size_t)ldab * (size_t)(j - 1)];
+		b[j - 1] = temp;
+	}
+	for (int j = n; j >= 1; j--) {
+		if (b[j - 1] != 0.0) {
+			const int l = kp1 - j;
+			b[j - 1] = b[j - 1] / ab[(size_t)kd + (size_t)ldab * (size_t)(j - 1)];
+			const real_t temp = b[j - 1];
+			const int i0 = j - kd > 1 ? j - kd : 1;
+			for (int i = j - 1; i >= i0; i--) b[i - 1] = b[i - 1] - temp * ab[(size_t)(l + i - 1) + (size_t)ldab * (size_t)(j - 1)];
+		}
+	}
+}
+
+// ------------------------------------------------------------------ 2D
+__global__ __launch_bounds__(256) void setup_cg2_kernel(const real_t *__restrict__ so, int II, int JJ, int nstncl,
+                                                         real_t *__restrict__ abd, int nabd1, int nabd2, int *info)
+{
+	const int I1 = II - 1, J1 = JJ - 1, I2 = I1 - 1;
+	const int n = I2 * (J1 - 1);
+	const size_t PS = (size_t)II * JJ;
+	for (int kk = threadIdx.x + 1; kk <= n; kk += blockDim.x) {
+		const int i = (kk - 1) % I2 + 2, j = (kk - 1) / I2 + 2; // 1-based
+		const size_t x = (size_t)(i - 1) + (size_t)II * (size_t)(j - 1);
+		ABD(II, kk) = so[KO * PS + x];
+		ABD(I1, kk) = -so[KW * PS + x];
+		ABD(3, kk) = nstncl == 5 ? -so[KNW * PS + x + 1] : 0.0;
+		ABD(2, kk) = -so[KS * PS + x];
+		ABD(1, kk) = nstncl == 5 ? -so[KSW * PS + x] : 0.0;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) *info = dpbtf2_upper(n, I1, abd, nabd1);
+}
+
+__global__ __launch_bounds__(64) void solve_cg2_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ,
+                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1)
+{
+	const int I1 = II - 1, J1 = JJ - 1, I2 = I1 - 1;
+	const int n = I2 * (J1 - 1);
+	for (int kk = threadIdx.x; kk < n; kk += blockDim.x) {
+		const int i = kk % I2 + 1, j = kk / I2 + 1; // 0-based
+		bbd[kk] = qf[(size_t)i + (size_t)II * j];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) dpbtrs_upper(n, I1, abd, nabd1, bbd);
+	__syncthreads();
+	for (int kk = threadIdx.x; kk < n; kk += blockDim.x) {
+		const int i = kk % I2 + 1, j = kk / I2 + 1;
+		q[(size_t)i + (size_t)II * j] = bbd[kk];
+	}
+}
+
+void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st)
+{
+	hipLaunchKernelGGL(setup_cg2_kernel, dim3(1), dim3(256), 0, st, so, II, JJ, nstncl, abd, nabd1, nabd2, info);
+}
+
+void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st)
+{
+	(void)nabd2;
+	hipLaunchKernelGGL(solve_cg2_kernel, dim3(1), dim3(64), 0, st, q, qf, II, JJ, abd, bbd, nabd1);
+}
+
+// ------------------------------------------------------------------ 3D
+__global__ __launch_bounds__(256) void setup_cg3_kernel(const real_t *__restrict__ so, int II, int JJ, int KK, int nstncl,
+                                                         real_t *__restrict__ abd, int nabd1, int nabd2, int *info)
+{
+	const int i1 = II - 1, j1 = JJ - 1, k1 = KK - 1, i2 = i1 - 1;
+	const int ibw = i2 * j1 + 1;
+	const int nxy = i2 * (j1 - 1), n = nxy * (k1 - 1);
+	const size_t sj = II, sk = (size_t)II * JJ, PS = sk * KK;
+	const bool full = nstncl == 14;
+	for (int kl = threadIdx.x + 1; kl <= n; kl += blockDim.x) {
+		const int t = kl - 1;
+		const int i = t % i2 + 2, j = (t / i2) % (j1 - 1) + 2, k = t / nxy + 2; // 1-based
+		const size_t x = (size_t)(i - 1) + sj * (size_t)(j - 1) + sk * (size_t)(k - 1);
+		ABD(ibw + 1, kl) = so[KP * PS + x];
+		ABD(ibw, kl) = -so[KPW * PS + x];
+		ABD(ibw - i1 + 3, kl) = full ? -so[KPNW * PS + x + 1] : 0.0;
+		ABD(ibw - i1 + 2, kl) = -so[KPS * PS + x];
+		ABD(ibw - i1 + 1, kl) = full ? -so[KPSW * PS + x] : 0.0;
+		ABD(ibw - (j1 - 2) * i2 + 2, kl) = full ? -so[KBNE * PS + x + 1 + sj] : 0.0;
+		ABD(ibw - (j1 - 2) * i2 + 1, kl) = full ? -so[KBN * PS + x + sj] : 0.0;
+		ABD(ibw - (j1 - 2) * i2, kl) = full ? -so[KBNW * PS + x + sj] : 0.0;
+		ABD(ibw - (j1 - 1) * i2 + 2, kl) = full ? -so[KBE * PS + x + 1] : 0.0;
+		ABD(ibw - (j1 - 1) * i2 + 1, kl) = -so[KB * PS + x];
+		ABD(ibw - (j1 - 1) * i2, kl) = full ? -so[KBW * PS + x] : 0.0;
+		ABD(3, kl) = full ? -so[KBSE * PS + x + 1] : 0.0;
+		ABD(2, kl) = full ? -so[KBS * PS + x] : 0.0;
+		ABD(1, kl) = full ? -so[KBSW * PS + x] : 0.0;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) *info = dpbtf2_upper(n, ibw, abd, nabd1);
+}
+
+__global__ __launch_bounds__(64) void solve_cg3_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ, int KK,
+                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1)
+{
+	const int i1 = II - 1, j1 = JJ - 1, k1 = KK - 1, i2 = i1 - 1;
+	const int ibw = i2 * j1 + 1;
+	const int nxy = i2 * (j1 - 1), n = nxy * (k1 - 1);
+	const size_t sj = II, sk = (size_t)II * JJ;
+	for (int t = threadIdx.x; t < n; t += blockDim.x) {
+		const int i = t % i2 + 1, j = (t / i2) % (j1 - 1) + 1, k = t / nxy + 1; // 0-based
+		bbd[t] = qf[(size_t)i + sj * j + sk * k];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) dpbtrs_upper(n, ibw, abd, nabd1, bbd);
+	__syncthreads();
+	for (int t = threadIdx.x; t < n; t += blockDim.x) {
+		const int i = t % i2 + 1, j = (t / i2) % (j1 - 1) + 1, k = t / nxy + 1;
+		q[(size_t)i + sj * j + sk * k] = bbd[t];
+	}
+}
+
+void setup_cg3(const real_t *so, int II, int JJ, int KK, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st)
+{
+	hipLaunchKernelGGL(setup_cg3_kernel, dim3(1), dim3(256), 0, st, so, II, JJ, KK, nstncl, abd, nabd1, nabd2, info);
+}
+
+void solve_cg3(real_t *q, const real_t *qf, int II, int JJ, int KK, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st)
+{
+	(void)nabd2;
+	hipLaunchKernelGGL(solve_cg3_kernel, dim3(1), dim3(64), 0, st, q, qf, II, JJ, KK, abd, bbd, nabd1);
+}
+
+} // namespace cedar_amd

@@ -84,7 +84,9 @@ void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st
 void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st);
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                    int II, int JJ, int nstncl, int updown, hipStream_t st);
-void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+// scratch: line-contiguous buffer of ylines_scratch_doubles(II,JJ) doubles in HBM
+size_t ylines_scratch_doubles(int II, int JJ);
+void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *scratch,
                    int II, int JJ, int nstncl, int updown, hipStream_t st);
 // cgsolve.hip
 void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);

@@ -1,0 +1,213 @@
+// Galerkin coarse-grid operator  A_c = P^T A P  built on the device.
+// Replaces BMG2_SymStd_SETUP_ITLI_ex (src/2d/ftn/BMG2_SymStd_SETUP_ITLI_ex.f90:94-331),
+// BMG3_SymStd_SETUP_ITLI27_ex (src/3d/ftn/BMG3_SymStd_SETUP_ITLI27_ex.f90:84-1888) and
+// BMG3_SymStd_SETUP_ITLI07_ex (src/3d/ftn/BMG3_SymStd_SETUP_ITLI07_ex.f90:84-1005).
+//
+// The reference spells the triple product out as thousands of lines of
+// closed-form sums.  Here it is evaluated from two small tables that encode
+// the reference's storage conventions:
+//   * slot s of a symmetric stencil stored at P couples P+A[s] with P+B[s]
+//     (read off BMG3_SymStd_relax_GS.f90:104-131 / BMG2_SymStd_relax_GS.f90:98-107);
+//   * the weight of coarse point c at fine point F(c)+d is the CI entry that
+//     interp_add applies there (BMG3_SymStd_interp_add.f90:100-240).
+// One lane per (coarse point, coarse slot):
+//   SOC(c,s) = -+ sum_{f1 in N(c+A[s])} P(f1,c+A[s]) sum_{f2 in N(c+B[s]), |f2-f1|<=1} A(f1,f2) P(f2,c+B[s])
+// Exactly the SO/CI entries the reference reads are read (ghost entries
+// included); the additions associate differently, so SOC agrees with the
+// reference to rounding (~4e-16 relative, tests/), not bit-for-bit.
+// Set-up runs once per solve; loads are L1/L2 hits shared by neighbouring lanes.
+#include "common.h"
+
+namespace cedar_amd {
+
+// ======================================================================= 2D
+__constant__ int A2x[5] = { 0, 0, 0, 0, 0 }, A2y[5] = { 0, 0, 0, 0, -1 };
+__constant__ int B2x[5] = { 0, -1, 0, -1, -1 }, B2y[5] = { 0, 0, -1, -1, 0 };
+
+#define CI2(ic, jc, s) ci[(size_t)((ic)-1) + (size_t)IIC * ((size_t)((jc)-1) + (size_t)JJC * (size_t)(s))]
+#define SO2(i, j, s) so[(size_t)((i)-1) + (size_t)IIF * ((size_t)((j)-1) + (size_t)JJF * (size_t)(s))]
+
+__device__ __forceinline__ real_t pw2(const real_t *__restrict__ ci, int IIC, int JJC, int ic, int jc, int dx, int dy)
+{
+	if (dx == 0 && dy == 0) return 1.0;
+	if (dy == 0) return dx < 0 ? CI2(ic, jc, LR) : CI2(ic + 1, jc, LL);
+	if (dx == 0) return dy < 0 ? CI2(ic, jc, LA) : CI2(ic, jc + 1, LB);
+	if (dx < 0 && dy < 0) return CI2(ic, jc, LNE);
+	if (dx > 0 && dy < 0) return CI2(ic + 1, jc, LNW);
+	if (dx < 0 && dy > 0) return CI2(ic, jc + 1, LSE);
+	return CI2(ic + 1, jc + 1, LSW);
+}
+
+__device__ __forceinline__ real_t aoff2(const real_t *__restrict__ so, int IIF, int JJF, int ifd, int i, int j, int dx, int dy)
+{
+	int si, sj, slot;
+	if (dy == 0) { slot = KW; si = dx < 0 ? i : i + 1; sj = j; }
+	else if (dx == 0) { slot = KS; si = i; sj = dy < 0 ? j : j + 1; }
+	else if (dx < 0 && dy < 0) { slot = KSW; si = i; sj = j; }
+	else if (dx > 0 && dy > 0) { slot = KSW; si = i + 1; sj = j + 1; }
+	else if (dx > 0 && dy < 0) { slot = KNW; si = i + 1; sj = j; }
+	else { slot = KNW; si = i; sj = j + 1; }
+	if (ifd == 1 && slot >= KSW) return 0.0;
+	if (si < 1 || si > IIF || sj < 1 || sj > JJF) return 0.0;
+	return SO2(si, sj, slot);
+}
+
+__global__ __launch_bounds__(256) void galerkin2_kernel(const real_t *__restrict__ so, real_t *__restrict__ soc,
+                                                         const real_t *__restrict__ ci, int IIF, int JJF,
+                                                         int IIC, int JJC, int ifd)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	const int s = t % 5, ic = t / 5 + 2, jc = blockIdx.y + 2; // 1-based coarse
+	if (ic > IIC - 1) return;
+	const int ic1 = ic + A2x[s], jc1 = jc + A2y[s], ic2 = ic + B2x[s], jc2 = jc + B2y[s];
+	const int i1 = 2 * (ic1 - 1), j1 = 2 * (jc1 - 1), i2 = 2 * (ic2 - 1), j2 = 2 * (jc2 - 1);
+	real_t acc = 0.0;
+	for (int dy = -1; dy <= 1; dy++)
+		for (int dx = -1; dx <= 1; dx++) {
+			const int fi = i1 + dx, fj = j1 + dy;
+			real_t row = 0.0;
+			bool any = false;
+			for (int ey = -1; ey <= 1; ey++)
+				for (int ex = -1; ex <= 1; ex++) {
+					const int rx = fi + ex - i2, ry = fj + ey - j2;
+					if (rx < -1 || rx > 1 || ry < -1 || ry > 1) continue;
+					const real_t p2 = pw2(ci, IIC, JJC, ic2, jc2, rx, ry);
+					if (ex == 0 && ey == 0) {
+						if (fi < 1 || fi > IIF || fj < 1 || fj > JJF) continue;
+						row += SO2(fi, fj, KO) * p2;
+					} else
+						row -= aoff2(so, IIF, JJF, ifd, fi, fj, ex, ey) * p2;
+					any = true;
+				}
+			if (any) acc += pw2(ci, IIC, JJC, ic1, jc1, dx, dy) * row;
+		}
+	soc[(size_t)(ic - 1) + (size_t)IIC * ((size_t)(jc - 1) + (size_t)JJC * (size_t)s)] = (s == KO) ? acc : -acc;
+}
+
+void galerkin2(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int IIC, int JJC,
+               int ifd, hipStream_t st)
+{
+	if (IIC < 3 || JJC < 3) return;
+	dim3 grid(((IIC - 2) * 5 + 255) / 256, JJC - 2);
+	hipLaunchKernelGGL(galerkin2_kernel, grid, dim3(256), 0, st, so, soc, ci, IIF, JJF, IIC, JJC, ifd);
+}
+#undef CI2
+#undef SO2
+
+// ======================================================================= 3D
+__constant__ signed char A3[14][3] = {
+	{ 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, // kp kpw kps kb kpsw
+	{ 0, -1, 0 },                                                    // kpnw
+	{ 0, 0, 0 },                                                     // kbw
+	{ 0, -1, 0 }, { 0, -1, 0 }, { -1, -1, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, // kbnw kbn kbne kbe kbse
+	{ 0, 0, 0 }, { 0, 0, 0 }                                         // kbs kbsw
+};
+__constant__ signed char B3[14][3] = {
+	{ 0, 0, 0 }, { -1, 0, 0 }, { 0, -1, 0 }, { 0, 0, -1 }, { -1, -1, 0 },
+	{ -1, 0, 0 },
+	{ -1, 0, -1 },
+	{ -1, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, -1, -1 },
+	{ 0, -1, -1 }, { -1, -1, -1 }
+};
+// weight of coarse c at fine F(c)+(dx,dy,dz): CI(c + (ox,oy,oz), slot); [dz+1][dy+1][dx+1][slot,ox,oy,oz]
+__constant__ signed char PW3[3][3][3][4] = {
+	{ { { LTNE, 0, 0, 0 }, { LYZNW, 0, 0, 0 }, { LTNW, 1, 0, 0 } },
+	  { { LXZNE, 0, 0, 0 }, { LXZA, 0, 0, 0 }, { LXZNW, 1, 0, 0 } },
+	  { { LTSE, 0, 1, 0 }, { LYZNE, 0, 1, 0 }, { LTSW, 1, 1, 0 } } },
+	{ { { LXYNE, 0, 0, 0 }, { LXYA, 0, 0, 0 }, { LXYNW, 1, 0, 0 } },
+	  { { LXYR, 0, 0, 0 }, { -1, 0, 0, 0 }, { LXYL, 1, 0, 0 } },
+	  { { LXYSE, 0, 1, 0 }, { LXYB, 0, 1, 0 }, { LXYSW, 1, 1, 0 } } },
+	{ { { LBNE, 0, 0, 1 }, { LYZSW, 0, 0, 1 }, { LBNW, 1, 0, 1 } },
+	  { { LXZSE, 0, 0, 1 }, { LXZB, 0, 0, 1 }, { LXZSW, 1, 0, 1 } },
+	  { { LBSE, 0, 1, 1 }, { LYZSE, 0, 1, 1 }, { LBSW, 1, 1, 1 } } }
+};
+// for a fine offset e = g - f: slot coupling f and g and its storage point relative to f
+// (derived from A3/B3 on the host at first use)
+__constant__ signed char OFF3[3][3][3][4];
+
+static void build_off3(signed char (*tab)[3][3][4])
+{
+	static const int A[14][3] = {
+		{ 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, -1, 0 }, { 0, 0, 0 },
+		{ 0, -1, 0 }, { 0, -1, 0 }, { -1, -1, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+	static const int B[14][3] = {
+		{ 0, 0, 0 }, { -1, 0, 0 }, { 0, -1, 0 }, { 0, 0, -1 }, { -1, -1, 0 }, { -1, 0, 0 }, { -1, 0, -1 },
+		{ -1, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { -1, -1, -1 } };
+	for (int s = 1; s < 14; s++) {
+		int ex = B[s][0] - A[s][0], ey = B[s][1] - A[s][1], ez = B[s][2] - A[s][2];
+		signed char *p = tab[ez + 1][ey + 1][ex + 1];
+		p[0] = (signed char)s; p[1] = (signed char)-A[s][0]; p[2] = (signed char)-A[s][1]; p[3] = (signed char)-A[s][2];
+		signed char *m = tab[-ez + 1][-ey + 1][-ex + 1];
+		m[0] = (signed char)s; m[1] = (signed char)-B[s][0]; m[2] = (signed char)-B[s][1]; m[3] = (signed char)-B[s][2];
+	}
+	tab[1][1][1][0] = 0; tab[1][1][1][1] = 0; tab[1][1][1][2] = 0; tab[1][1][1][3] = 0;
+}
+
+#define CI3(ic, jc, kc, s) ci[(size_t)((ic)-1) + (size_t)IIC * ((size_t)((jc)-1) + (size_t)JJC * ((size_t)((kc)-1) + (size_t)KKC * (size_t)(s)))]
+#define SO3(i, j, k, s) so[(size_t)((i)-1) + (size_t)IIF * ((size_t)((j)-1) + (size_t)JJF * ((size_t)((k)-1) + (size_t)KKF * (size_t)(s)))]
+
+__device__ __forceinline__ real_t pw3(const real_t *__restrict__ ci, int IIC, int JJC, int KKC,
+                                      int ic, int jc, int kc, int dx, int dy, int dz)
+{
+	const signed char *e = PW3[dz + 1][dy + 1][dx + 1];
+	if (e[0] < 0) return 1.0;
+	return CI3(ic + e[1], jc + e[2], kc + e[3], e[0]);
+}
+
+__global__ __launch_bounds__(256) void galerkin3_kernel(const real_t *__restrict__ so, real_t *__restrict__ soc,
+                                                         const real_t *__restrict__ ci, int IIF, int JJF, int KKF,
+                                                         int IIC, int JJC, int KKC, int ifd)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	const int s = t % 14, ic = t / 14 + 2, jc = blockIdx.y + 2, kc = blockIdx.z + 2;
+	if (ic > IIC - 1) return;
+	const int c1x = ic + A3[s][0], c1y = jc + A3[s][1], c1z = kc + A3[s][2];
+	const int c2x = ic + B3[s][0], c2y = jc + B3[s][1], c2z = kc + B3[s][2];
+	const int f1x = 2 * (c1x - 1), f1y = 2 * (c1y - 1), f1z = 2 * (c1z - 1);
+	const int f2x = 2 * (c2x - 1), f2y = 2 * (c2y - 1), f2z = 2 * (c2z - 1);
+	real_t acc = 0.0;
+	for (int dz = -1; dz <= 1; dz++)
+		for (int dy = -1; dy <= 1; dy++)
+			for (int dx = -1; dx <= 1; dx++) {
+				const int fi = f1x + dx, fj = f1y + dy, fk = f1z + dz;
+				// f2 = f1 + e must lie in N(c2): e in [lo, hi] per axis
+				const int exl = max(-1, f2x - 1 - fi), exh = min(1, f2x + 1 - fi);
+				const int eyl = max(-1, f2y - 1 - fj), eyh = min(1, f2y + 1 - fj);
+				const int ezl = max(-1, f2z - 1 - fk), ezh = min(1, f2z + 1 - fk);
+				real_t row = 0.0;
+				bool any = false;
+				for (int ez = ezl; ez <= ezh; ez++)
+					for (int ey = eyl; ey <= eyh; ey++)
+						for (int ex = exl; ex <= exh; ex++) {
+							const signed char *o = OFF3[ez + 1][ey + 1][ex + 1];
+							const int slot = o[0];
+							if (ifd == 1 && slot > KB) continue;
+							const int si = fi + o[1], sj = fj + o[2], sk = fk + o[3];
+							if (si < 1 || si > IIF || sj < 1 || sj > JJF || sk < 1 || sk > KKF) continue;
+							const real_t p2 = pw3(ci, IIC, JJC, KKC, c2x, c2y, c2z, fi + ex - f2x, fj + ey - f2y, fk + ez - f2z);
+							if (slot == 0) row += SO3(si, sj, sk, KP) * p2;
+							else row -= SO3(si, sj, sk, slot) * p2;
+							any = true;
+						}
+				if (any) acc += pw3(ci, IIC, JJC, KKC, c1x, c1y, c1z, dx, dy, dz) * row;
+			}
+	soc[(size_t)(ic - 1) + (size_t)IIC * ((size_t)(jc - 1) + (size_t)JJC * ((size_t)(kc - 1) + (size_t)KKC * (size_t)s))]
+	    = (s == KP) ? acc : -acc;
+}
+
+void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
+               int IIC, int JJC, int KKC, int ifd, hipStream_t st)
+{
+	if (IIC < 3 || JJC < 3 || KKC < 3) return;
+	static bool ready = false;
+	if (!ready) {
+		signed char tab[3][3][3][4];
+		build_off3(tab);
+		CEDAR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(OFF3), tab, sizeof(tab)));
+		ready = true;
+	}
+	dim3 grid(((IIC - 2) * 14 + 255) / 256, JJC - 2, KKC - 2);
+	hipLaunchKernelGGL(galerkin3_kernel, grid, dim3(256), 0, st, so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd);
+}
+
+} // namespace cedar_amd

@@ -1,0 +1,327 @@
+// Zebra line relaxation in 2D (x- and y-lines) and its factorisation set-up.
+// Replaces BMG2_SymStd_SETUP_lines_x/_y (src/2d/ftn/BMG2_SymStd_SETUP_lines_x.f90:68-87,
+// ..._y.f90:69-87), BMG2_SymStd_relax_lines_x (..._relax_lines_x.f90:82-162) and
+// BMG2_SymStd_relax_lines_y (..._relax_lines_y.f90:77-168), plus the LAPACK
+// calls inside them (DPTTRF / DPTTRS; system LAPACK in the reference, not
+// vendored -- the published netlib recurrences are restated here:
+//   factor: e_i <- e_i/d_i ; d_{i+1} <- d_{i+1} - e_i*(e_i d_i)
+//   solve : b_i <- b_i - b_{i-1} e_{i-1} ;  b_n <- b_n/d_n ; b_i <- b_i/d_i - b_{i+1} e_i ).
+//
+// Set-up (once per solve): one lane per line runs the DPTTRF recurrence
+// sequentially in the reference's operation order => bit-identical factors.
+//
+// Relaxation (hot path, 64 algorithmic B/DOF per direction): all lines of one
+// colour are independent.  One workgroup owns one line held in LDS (<= 64 KB);
+// both DPTTRS sweeps are first-order affine recurrences y_i = a_i y_{i-1} + c_i,
+// evaluated tile by tile (BS consecutive unknowns) with a Kogge-Stone scan of
+// the affine maps over wavefront shuffles, a 4-entry cross-wave fix-up in LDS
+// and a scalar carry between tiles.  The scan re-associates the recurrence, so
+// results agree with the sequential DPTTRS to rounding (like one vendor LAPACK
+// against another), not bit-for-bit; tolerances are stated in tests/.
+// y-lines are strided in memory: their right-hand sides are gathered through
+// an LDS tile transpose into a line-contiguous scratch (the same transposed
+// layout the reference uses for the y factors, SOR(JJ,II,2)), solved by the
+// same kernel, and scattered back.
+#include "common.h"
+
+namespace cedar_amd {
+
+// ------------------------------------------------------------------ set-up
+__global__ void lines_fill_x(const real_t *__restrict__ so, real_t *__restrict__ sor, int II, int JJ)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1;
+	if (i > II - 2) return;
+	const size_t PS = (size_t)II * JJ, x = (size_t)i + (size_t)II * j;
+	sor[PS + x] = -so[KW * PS + x];
+	sor[x] = so[KO * PS + x];
+}
+
+__global__ void lines_fill_y(const real_t *__restrict__ so, real_t *__restrict__ sor, int II, int JJ)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1;
+	if (i > II - 2) return;
+	const size_t PS = (size_t)II * JJ, x = (size_t)i + (size_t)II * j;
+	const size_t xt = (size_t)j + (size_t)JJ * i; // SOR(JJ,II,2)
+	sor[PS + xt] = -so[KS * PS + x];
+	sor[xt] = so[KO * PS + x];
+}
+
+// one lane per line; d = sor(:,line,1) from index 1 (0-based), e = sor(:,line,2) from index 2
+__global__ void lines_factor(real_t *__restrict__ sor, int n /*unknowns*/, int ld /*line stride*/, int nlines, size_t PS)
+{
+	const int l = blockIdx.x * blockDim.x + threadIdx.x;
+	if (l >= nlines) return;
+	real_t *d = sor + (size_t)ld * (l + 1) + 1;
+	real_t *e = sor + PS + (size_t)ld * (l + 1) + 2;
+	real_t di = d[0];
+	for (int i = 0; i < n - 1; i++) {
+		if (di <= 0.0) return; // DPTTRF: INFO = i+1, factorisation stops
+		const real_t ei = e[i];
+		const real_t en = ei / di;
+		e[i] = en;
+		di = d[i + 1] - en * ei;
+		d[i + 1] = di;
+	}
+}
+
+void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st)
+{
+	if (II < 3 || JJ < 3) return;
+	dim3 grid((II - 2 + 255) / 256, JJ - 2);
+	hipLaunchKernelGGL(lines_fill_x, grid, dim3(256), 0, st, so, sor, II, JJ);
+	hipLaunchKernelGGL(lines_factor, dim3((JJ - 2 + 63) / 64), dim3(64), 0, st, sor, II - 2, II, JJ - 2, (size_t)II * JJ);
+}
+
+void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st)
+{
+	if (II < 3 || JJ < 3) return;
+	dim3 grid((II - 2 + 255) / 256, JJ - 2);
+	hipLaunchKernelGGL(lines_fill_y, grid, dim3(256), 0, st, so, sor, II, JJ);
+	hipLaunchKernelGGL(lines_factor, dim3((II - 2 + 63) / 64), dim3(64), 0, st, sor, JJ - 2, JJ, II - 2, (size_t)II * JJ);
+}
+
+// ------------------------------------------------------------------ affine scan
+// inclusive scan over the workgroup of the maps y -> a*y + c (element order = thread order);
+// returns the value of this thread's unknown given the carry entering the tile.
+template <int BS>
+__device__ __forceinline__ real_t affine_tile(real_t a, real_t c, real_t carry, real_t *wa, real_t *wc)
+{
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const real_t ap = __shfl_up(a, off, 64), cp = __shfl_up(c, off, 64);
+		if (lane >= off) {
+			c = a * cp + c;
+			a = a * ap;
+		}
+	}
+	constexpr int NW = BS / 64;
+	if (NW > 1) {
+		if (lane == 63) { wa[w] = a; wc[w] = c; }
+		__syncthreads();
+		real_t y = carry;
+		for (int u = 0; u < w; u++) y = wa[u] * y + wc[u];
+		carry = y;
+	}
+	return a * carry + c;
+}
+
+// Solve L D L^T x = y for the line held in LDS `y[0..n)`; d[0..n), e[0..n-1) contiguous in HBM.
+template <int BS>
+__device__ __forceinline__ void line_pttrs(real_t *y, int n, const real_t *__restrict__ d, const real_t *__restrict__ e,
+                                           real_t *wa, real_t *wc, real_t *carry_slot)
+{
+	// forward: y_i = y_i - e_{i-1} y_{i-1}
+	real_t carry = 0.0;
+	for (int base = 0; base < n; base += BS) {
+		const int i = base + threadIdx.x;
+		real_t a = 0.0, c = 0.0;
+		if (i < n) {
+			c = y[i];
+			a = i > 0 ? -e[i - 1] : 0.0;
+		}
+		const real_t v = affine_tile<BS>(a, c, carry, wa, wc);
+		if (i < n) y[i] = v;
+		if (threadIdx.x == BS - 1) *carry_slot = v;
+		__syncthreads();
+		carry = *carry_slot;
+		__syncthreads();
+	}
+	// backward: x_i = y_i/d_i - e_i x_{i+1}, i = n-1 .. 0 (thread order = reversed index)
+	carry = 0.0;
+	for (int base = 0; base < n; base += BS) {
+		const int r = base + threadIdx.x; // reversed position
+		const int i = n - 1 - r;
+		real_t a = 0.0, c = 0.0;
+		if (r < n) {
+			c = y[i] / d[i];
+			a = r > 0 ? -e[i] : 0.0;
+		}
+		const real_t v = affine_tile<BS>(a, c, carry, wa, wc);
+		if (r < n) y[i] = v;
+		if (threadIdx.x == BS - 1) *carry_slot = v;
+		__syncthreads();
+		carry = *carry_slot;
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------ x-lines
+template <int BS, bool NINE>
+__global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                            real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                            int II, int JJ, int jb, int nlines)
+{
+	extern __shared__ __attribute__((aligned(16))) real_t lds[];
+	real_t *y = lds, *wa = lds + (II - 2), *wc = wa + 4, *cs = wc + 4;
+	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nlines);
+	if (L >= (unsigned)nlines) return;
+	const size_t sj = II, PS = (size_t)II * JJ;
+	const size_t row = (size_t)(1 + jb + 2 * (int)L) * sj;
+	const int n = II - 2;
+	// right-hand side (relax_lines_x.f90:106-111 / :128-129), reference term order
+	for (int t = threadIdx.x; t < n; t += BS) {
+		const size_t x = row + 1 + t;
+		real_t s = qf[x];
+		s = s + so[KS * PS + x] * q[x - sj];
+		s = s + so[KS * PS + x + sj] * q[x + sj];
+		if (NINE) {
+			s = s + so[KSW * PS + x] * q[x - 1 - sj];
+			s = s + so[KNW * PS + x + 1] * q[x + 1 - sj];
+			s = s + so[KNW * PS + x + sj] * q[x - 1 + sj];
+			s = s + so[KSW * PS + x + 1 + sj] * q[x + 1 + sj];
+		}
+		y[t] = s;
+	}
+	__syncthreads();
+	line_pttrs<BS>(y, n, sor + row + 1, sor + PS + row + 2, wa, wc, cs);
+	for (int t = threadIdx.x; t < n; t += BS) q[row + 1 + t] = y[t];
+}
+
+static bool lds_ok(int n, const char *who)
+{
+	if ((size_t)(n + 16) * sizeof(real_t) > 160 * 1024 - 512) {
+		fprintf(stderr, "[cedar_amd] %s: line of %d unknowns does not fit the 160 KB LDS\n", who, n);
+		abort();
+	}
+	return true;
+}
+
+template <int BS>
+static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
+                     int nstncl, int jb, hipStream_t st)
+{
+	int nlines = (JJ - 2 - jb + 1) / 2;
+	if (nlines <= 0) return;
+	size_t shm = (size_t)(II - 2 + 16) * sizeof(real_t);
+	if (nstncl == 5) {
+		auto k = relax_lines_x_kernel<BS, true>;
+		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+		hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines);
+	} else {
+		auto k = relax_lines_x_kernel<BS, false>;
+		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+		hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines);
+	}
+}
+
+void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int nstncl, int updown, hipStream_t st)
+{
+	if (II < 3 || JJ < 3) return;
+	lds_ok(II - 2, "relax_lines_x");
+	for (int c = 0; c < 2; c++) {
+		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
+		int jb = (updown == BMG_DOWN) ? 1 - c : c;
+		if (II - 2 <= 64) launch_x<64>(so, qf, q, sor, II, JJ, nstncl, jb, st);
+		else launch_x<256>(so, qf, q, sor, II, JJ, nstncl, jb, st);
+	}
+}
+
+// ------------------------------------------------------------------ y-lines
+// gather: bt[l*ldt + (j-1)] = rhs(i_l, j) for the colour's lines i_l = 1+ib+2l (0-based), j = 1..JJ-2
+template <bool NINE>
+__global__ __launch_bounds__(256) void ylines_rhs_T(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                     const real_t *__restrict__ q, real_t *__restrict__ bt,
+                                                     int II, int JJ, int ib, int nlines, int ldt)
+{
+	__shared__ real_t tile[32][33];
+	const int l0 = blockIdx.x * 32, j0 = blockIdx.y * 32; // tile origin (line index, j-1)
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+	const size_t sj = II, PS = (size_t)II * JJ;
+	for (int r = ty; r < 32; r += 8) {
+		const int l = l0 + tx, j = j0 + r + 1;
+		real_t s = 0.0;
+		if (l < nlines && j <= JJ - 2) {
+			const size_t x = (size_t)(1 + ib + 2 * l) + sj * (size_t)j;
+			// relax_lines_y.f90:103-107 / :133-134, reference term order
+			s = qf[x];
+			s = s + so[KW * PS + x] * q[x - 1];
+			s = s + so[KW * PS + x + 1] * q[x + 1];
+			if (NINE) {
+				s = s + so[KSW * PS + x] * q[x - 1 - sj];
+				s = s + so[KNW * PS + x + 1] * q[x + 1 - sj];
+				s = s + so[KNW * PS + x + sj] * q[x - 1 + sj];
+				s = s + so[KSW * PS + x + 1 + sj] * q[x + 1 + sj];
+			}
+		}
+		tile[r][tx] = s;
+	}
+	__syncthreads();
+	for (int r = ty; r < 32; r += 8) {
+		const int l = l0 + r, jj = j0 + tx; // jj = j-1
+		if (l < nlines && jj < JJ - 2) bt[(size_t)l * ldt + jj] = tile[tx][r];
+	}
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, const real_t *__restrict__ sor,
+                                                    int II, int JJ, int ib, int nlines, int ldt)
+{
+	extern __shared__ __attribute__((aligned(16))) real_t lds[];
+	const int n = JJ - 2;
+	real_t *y = lds, *wa = lds + n, *wc = wa + 4, *cs = wc + 4;
+	const unsigned L = blockIdx.x;
+	if (L >= (unsigned)nlines) return;
+	const size_t PS = (size_t)II * JJ;
+	const int i = 1 + ib + 2 * (int)L; // 0-based line position
+	real_t *line = bt + (size_t)L * ldt;
+	for (int t = threadIdx.x; t < n; t += BS) y[t] = line[t];
+	__syncthreads();
+	// SOR(JJ,II,2): d = SOR(2.., i) , e = SOR(3.., i, 2)
+	line_pttrs<BS>(y, n, sor + (size_t)JJ * i + 1, sor + PS + (size_t)JJ * i + 2, wa, wc, cs);
+	for (int t = threadIdx.x; t < n; t += BS) line[t] = y[t];
+}
+
+__global__ __launch_bounds__(256) void ylines_scatter_T(const real_t *__restrict__ bt, real_t *__restrict__ q,
+                                                         int II, int JJ, int ib, int nlines, int ldt)
+{
+	__shared__ real_t tile[32][33];
+	const int l0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	for (int r = ty; r < 32; r += 8) {
+		const int l = l0 + r, jj = j0 + tx;
+		tile[r][tx] = (l < nlines && jj < JJ - 2) ? bt[(size_t)l * ldt + jj] : 0.0;
+	}
+	__syncthreads();
+	for (int r = ty; r < 32; r += 8) {
+		const int l = l0 + tx, j = j0 + r + 1;
+		if (l < nlines && j <= JJ - 2) q[(size_t)(1 + ib + 2 * l) + (size_t)II * j] = tile[tx][r];
+	}
+}
+
+size_t ylines_scratch_doubles(int II, int JJ)
+{
+	const int n = JJ - 2;
+	return (size_t)((II - 2 + 1) / 2) * (size_t)((n + 15) & ~15) + 16;
+}
+
+void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *bt,
+                   int II, int JJ, int nstncl, int updown, hipStream_t st)
+{
+	if (II < 3 || JJ < 3) return;
+	lds_ok(JJ - 2, "relax_lines_y");
+	const int n = JJ - 2;
+	const int ldt = (n + 15) & ~15;
+	const size_t shm = (size_t)(n + 16) * sizeof(real_t);
+	for (int c = 0; c < 2; c++) {
+		int ib = (updown == BMG_DOWN) ? 1 - c : c; // DOWN: I = 3,5,.. first
+		int nlines = (II - 2 - ib + 1) / 2;
+		if (nlines <= 0) continue;
+		dim3 tg((nlines + 31) / 32, (n + 31) / 32);
+		if (nstncl == 5)
+			hipLaunchKernelGGL(ylines_rhs_T<true>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
+		else
+			hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
+		if (n <= 64) {
+			hipLaunchKernelGGL(ylines_solve<64>, dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt);
+		} else {
+			auto k = ylines_solve<256>;
+			if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+			hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt);
+		}
+		hipLaunchKernelGGL(ylines_scatter_T, tg, dim3(256), 0, st, bt, q, II, JJ, ib, nlines, ldt);
+	}
+}
+
+} // namespace cedar_amd

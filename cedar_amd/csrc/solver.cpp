@@ -1,0 +1,394 @@
+// C-ABI layer 2: device-resident multilevel hierarchy and V-cycle.
+// Restates the orchestration of the reference's serial solvers on top of the
+// HIP kernels; every level array lives in HBM for the whole solve, only norms
+// (one double per iteration) cross PCIe.
+//   level sizing / allocation : include/cedar/2d/solver.h:57-116, include/cedar/3d/solver.h:54-123
+//   set-up loop               : include/cedar/multilevel.h:243-265 (interp -> Galerkin -> relax set-up)
+//   V-cycle                   : include/cedar/cycle/vcycle.h:57-115
+//   smoothers                 : include/cedar/multilevel.h:165-222 (pre = DOWN, post = UP; line-xy: x,y / y,x)
+//   solve loop                : include/cedar/multilevel.h:268-298
+// The V-cycle is a fixed launch sequence for a given (x,b) pair; it is captured
+// once into a hipGraph and replayed, which removes the per-launch host cost
+// that dominates the coarse levels (a 2D 4096^2 cycle is ~130 launches).
+#include "../../include/cedar_amd.h"
+#include "common.h"
+#include "stage.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace cedar_amd;
+
+namespace {
+
+struct Level {
+	int nx = 0, ny = 0, nz = 1;
+	int II = 0, JJ = 0, KK = 1;
+	int nst = 0;
+	size_t npts = 0;
+	real_t *A = nullptr;
+	bool ownA = true;
+	real_t *P = nullptr;
+	real_t *x = nullptr, *b = nullptr, *res = nullptr;
+	real_t *SOR0 = nullptr, *SOR1 = nullptr;
+	real_t *yscr = nullptr; // y-line scratch
+};
+
+real_t *dalloc(size_t n)
+{
+	void *p = nullptr;
+	size_t bytes = (n ? n : 1) * sizeof(real_t);
+	CEDAR_HIP_CHECK(hipMalloc(&p, bytes));
+	CEDAR_HIP_CHECK(hipMemsetAsync(p, 0, bytes, current_stream()));
+	return static_cast<real_t *>(p);
+}
+
+} // namespace
+
+struct cedar_amd_solver {
+	int nd = 2;
+	cedar_amd_settings st;
+	std::vector<Level> lv;
+	real_t *ABD = nullptr, *bbd = nullptr;
+	int nabd1 = 0, nabd2 = 0;
+	int *dinfo = nullptr;
+	real_t *red = nullptr; // reduction scratch (4096 partials + result)
+	// captured V-cycle
+	hipGraphExec_t gexec = nullptr;
+	const real_t *gx = nullptr, *gb = nullptr;
+	hipStream_t gstream = nullptr;
+	bool use_graph = true;
+};
+
+namespace {
+
+int compute_num_levels(int nd, len_t nx, len_t ny, len_t nz, int min_coarse)
+{
+	// float nxc = (nx-1)/(1<<ng) + 1 with unsigned integer division; do { } while (min >= min_coarse)
+	int ng = 0;
+	float m;
+	do {
+		ng++;
+		float nxc = (float)((nx - 1) / (1u << ng) + 1);
+		float nyc = (float)((ny - 1) / (1u << ng) + 1);
+		m = nxc < nyc ? nxc : nyc;
+		if (nd == 3) {
+			float nzc = (float)((nz - 1) / (1u << ng) + 1);
+			m = m < nzc ? m : nzc;
+		}
+	} while (m >= (float)min_coarse);
+	return ng;
+}
+
+void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, bool lines_y)
+{
+	L.nx = nx; L.ny = ny; L.nz = nd == 3 ? nz : 1;
+	L.II = nx + 2; L.JJ = ny + 2; L.KK = nd == 3 ? nz + 2 : 1;
+	L.nst = nst;
+	L.npts = (size_t)L.II * L.JJ * L.KK;
+	L.res = dalloc(L.npts);
+	L.SOR0 = dalloc(L.npts * 2);
+	if (lines_y) {
+		L.SOR1 = dalloc(L.npts * 2);
+		L.yscr = dalloc(ylines_scratch_doubles(L.II, L.JJ));
+	}
+	if (coarse) {
+		L.A = dalloc(L.npts * nst);
+		L.P = dalloc(L.npts * (nd == 3 ? 26 : 8));
+		L.x = dalloc(L.npts);
+		L.b = dalloc(L.npts);
+	}
+}
+
+void residual(const cedar_amd_solver *s, const Level &L, const real_t *x, const real_t *b, real_t *r, hipStream_t st)
+{
+	if (s->nd == 2) residual2(L.A, b, x, r, L.II, L.JJ, L.nst, st);
+	else residual3(L.A, b, x, r, L.II, L.JJ, L.KK, L.nst, st);
+}
+
+void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *b, int updown, int n, hipStream_t st)
+{
+	for (int it = 0; it < n; it++) {
+		if (s->nd == 3) {
+			relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
+			continue;
+		}
+		switch (s->st.relaxation) {
+		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
+		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
+		case CEDAR_AMD_RELAX_LINE_Y: relax_lines_y(L.A, b, x, L.SOR0, L.yscr, L.II, L.JJ, L.nst, updown, st); break;
+		default:
+			if (updown == BMG_DOWN) {
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st);
+				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st);
+			} else {
+				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st);
+			}
+		}
+	}
+}
+
+void coarse_solve(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
+{
+	const Level &C = s->lv.back();
+	if (s->nd == 2) solve_cg2(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
+	else solve_cg3(x, b, C.II, C.JJ, C.KK, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
+}
+
+void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_t st)
+{
+	Level &L = s->lv[lvl], &K = s->lv[lvl + 1];
+	smooth(s, L, x, b, BMG_DOWN, s->st.nrelax_pre, st);
+	residual(s, L, x, b, L.res, st);
+	if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
+	CEDAR_HIP_CHECK(hipMemsetAsync(K.x, 0, K.npts * sizeof(real_t), st)); // coarse_x.set(0.0)
+	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
+	else ncycle(s, lvl + 1, K.x, K.b, st);
+	if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
+	smooth(s, L, x, b, BMG_UP, s->st.nrelax_post, st);
+}
+
+void cycle_launch(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
+{
+	if (s->lv.size() == 1) coarse_solve(s, x, b, st); // vcycle.h:37-38
+	else ncycle(s, 0, x, b, st);
+}
+
+// run one V-cycle on device pointers: graph replay when possible
+void cycle_dev(cedar_amd_solver *s, real_t *x, const real_t *b)
+{
+	hipStream_t st = current_stream();
+	if (!s->use_graph) {
+		cycle_launch(s, x, b, st);
+		return;
+	}
+	if (s->gexec && (s->gx != x || s->gb != b)) {
+		CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
+		s->gexec = nullptr;
+	}
+	if (!s->gexec) {
+		if (!s->gstream) CEDAR_HIP_CHECK(hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking));
+		// one eager cycle first is NOT wanted (it would change x); capture records without executing
+		CEDAR_HIP_CHECK(hipStreamSynchronize(st));
+		hipGraph_t g = nullptr;
+		CEDAR_HIP_CHECK(hipStreamBeginCapture(s->gstream, hipStreamCaptureModeThreadLocal));
+		cycle_launch(s, x, b, s->gstream);
+		CEDAR_HIP_CHECK(hipStreamEndCapture(s->gstream, &g));
+		CEDAR_HIP_CHECK(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
+		CEDAR_HIP_CHECK(hipGraphDestroy(g));
+		s->gx = x; s->gb = b;
+	}
+	CEDAR_HIP_CHECK(hipGraphLaunch(s->gexec, st));
+}
+
+double l2_dev(cedar_amd_solver *s, const Level &L, const real_t *v)
+{
+	sumsq_interior(v, L.II, L.JJ, L.KK, s->red, s->red + 4096, current_stream());
+	double ss = 0;
+	CEDAR_HIP_CHECK(hipMemcpyAsync(&ss, s->red + 4096, sizeof(double), hipMemcpyDeviceToHost, current_stream()));
+	CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream()));
+	return std::sqrt(ss);
+}
+
+} // namespace
+
+extern "C" {
+
+void cedar_amd_default_settings(cedar_amd_settings *s)
+{
+	s->relaxation = CEDAR_AMD_RELAX_POINT;
+	s->nrelax_pre = 2;
+	s->nrelax_post = 1;
+	s->num_levels = -1;
+	s->max_iter = 10;
+	s->tol = 1e-8;
+	s->min_coarse = 3;
+}
+
+cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil,
+                                          const real_t *so, int own_device_so,
+                                          const cedar_amd_settings *settings)
+{
+	hipStream_t st = current_stream();
+	cedar_amd_solver *s = new cedar_amd_solver;
+	s->nd = nd;
+	if (settings) s->st = *settings;
+	else cedar_amd_default_settings(&s->st);
+	if (nd == 3 && s->st.relaxation != CEDAR_AMD_RELAX_POINT) {
+		char msg[] = "cedar_amd_solver_create: 3D supports point relaxation only (plane relaxation is out of scope)";
+		print_error(msg);
+		s->st.relaxation = CEDAR_AMD_RELAX_POINT;
+	}
+	if (const char *e = getenv("CEDAR_AMD_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+	int nlev = compute_num_levels(nd, nx, ny, nz, s->st.min_coarse);
+	if (s->st.num_levels > 0) {
+		if (s->st.num_levels > nlev) {
+			char msg[] = "too many levels specified";
+			print_error(msg);
+		} else
+			nlev = s->st.num_levels;
+	}
+	s->lv.resize(nlev);
+	const bool ly = nd == 2 && (s->st.relaxation == CEDAR_AMD_RELAX_LINE_XY || s->st.relaxation == CEDAR_AMD_RELAX_LINE_Y);
+	level_init(s->lv[0], nd, (int)nx, (int)ny, (int)nz, nstencil, false, ly);
+	Level &F0 = s->lv[0];
+	if (own_device_so && is_device_ptr(so)) {
+		F0.A = const_cast<real_t *>(so);
+		F0.ownA = false;
+	} else {
+		F0.A = dalloc(F0.npts * nstencil);
+		CEDAR_HIP_CHECK(hipMemcpyAsync(F0.A, so, F0.npts * nstencil * sizeof(real_t),
+		                               is_device_ptr(so) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+	}
+	for (int l = 1; l < nlev; l++) {
+		const Level &F = s->lv[l - 1];
+		int nxc = (int)((F.nx - 1) / 2. + 1), nyc = (int)((F.ny - 1) / 2. + 1);
+		int nzc = nd == 3 ? (int)((F.nz - 1) / 2. + 1) : 1;
+		level_init(s->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, true, ly);
+	}
+	const Level &C = s->lv.back();
+	if (nd == 2) { s->nabd1 = C.nx + 2; s->nabd2 = C.nx * C.ny; }
+	else { s->nabd1 = C.nx * (C.ny + 1) + 2; s->nabd2 = C.nx * C.ny * C.nz; }
+	s->ABD = dalloc((size_t)s->nabd1 * s->nabd2);
+	s->bbd = dalloc(s->nabd2);
+	s->red = dalloc(4100);
+	CEDAR_HIP_CHECK(hipMalloc((void **)&s->dinfo, 64));
+	CEDAR_HIP_CHECK(hipMemsetAsync(s->dinfo, 0, 64, st));
+
+	for (int l = 0; l < nlev - 1; l++) {
+		Level &F = s->lv[l], &K = s->lv[l + 1];
+		if (nd == 2) {
+			int ifd = F.nst == 3;
+			setup_interp2(F.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, st);
+			galerkin2(F.A, K.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, st);
+			switch (s->st.relaxation) {
+			case CEDAR_AMD_RELAX_POINT: setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, 1, st); break;
+			case CEDAR_AMD_RELAX_LINE_X: setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st); break;
+			case CEDAR_AMD_RELAX_LINE_Y: setup_lines_y(F.A, F.SOR0, F.II, F.JJ, st); break;
+			default:
+				setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st);
+				setup_lines_y(F.A, F.SOR1, F.II, F.JJ, st);
+			}
+		} else {
+			int ifd = F.nst == 4;
+			setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
+			galerkin3(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
+			setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, F.KK, st);
+		}
+	}
+	if (nd == 2) setup_cg2(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
+	else setup_cg3(C.A, C.II, C.JJ, C.KK, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
+	int info = 0;
+	CEDAR_HIP_CHECK(hipMemcpyAsync(&info, s->dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+	CEDAR_HIP_CHECK(hipStreamSynchronize(st));
+	if (info != 0) {
+		char msg[] = "Coarse grid Cholesky decomp failed!";
+		print_error(msg);
+	}
+	return s;
+}
+
+void cedar_amd_solver_destroy(cedar_amd_solver *s)
+{
+	if (!s) return;
+	CEDAR_HIP_CHECK(hipDeviceSynchronize());
+	if (s->gexec) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
+	if (s->gstream) CEDAR_HIP_CHECK(hipStreamDestroy(s->gstream));
+	for (size_t l = 0; l < s->lv.size(); l++) {
+		Level &L = s->lv[l];
+		if (L.ownA) (void)hipFree(L.A);
+		(void)hipFree(L.P); (void)hipFree(L.res); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.yscr);
+		if (l > 0) { (void)hipFree(L.x); (void)hipFree(L.b); }
+	}
+	(void)hipFree(s->ABD); (void)hipFree(s->bbd); (void)hipFree(s->red); (void)hipFree(s->dinfo);
+	delete s;
+}
+
+int cedar_amd_solver_nlevels(const cedar_amd_solver *s) { return (int)s->lv.size(); }
+
+void cedar_amd_solver_level_dims(const cedar_amd_solver *s, int lvl, len_t *nx, len_t *ny, len_t *nz)
+{
+	*nx = s->lv[lvl].nx; *ny = s->lv[lvl].ny; *nz = s->lv[lvl].nz;
+}
+
+size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what, real_t *out)
+{
+	const Level &L = s->lv[lvl];
+	const real_t *src = nullptr;
+	size_t n = 0;
+	if (!strcmp(what, "A")) { src = L.A; n = L.npts * L.nst; }
+	else if (!strcmp(what, "P")) { src = L.P; n = L.P ? L.npts * (s->nd == 3 ? 26 : 8) : 0; }
+	else if (!strcmp(what, "SOR0")) { src = L.SOR0; n = L.npts * 2; }
+	else if (!strcmp(what, "SOR1")) { src = L.SOR1; n = L.SOR1 ? L.npts * 2 : 0; }
+	else if (!strcmp(what, "ABD")) { src = s->ABD; n = (size_t)s->nabd1 * s->nabd2; }
+	if (out && n) cedar_amd_memcpy_d2h(out, src, n * sizeof(real_t));
+	return n;
+}
+
+void cedar_amd_solver_vcycle(cedar_amd_solver *s, real_t *x, const real_t *b)
+{
+	const Level &L = s->lv[0];
+	Staged sx(x, L.npts, true, true), sb(b, L.npts, true, false);
+	if (sx.staged() || sb.staged()) {
+		// staging buffers change from call to call: launch eagerly
+		cycle_launch(s, sx.get(), sb.get(), current_stream());
+	} else
+		cycle_dev(s, sx.get(), sb.get());
+}
+
+int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real_t *rel)
+{
+	Level &L = s->lv[0];
+	Staged sx(x, L.npts, true, true), sb(b, L.npts, true, false);
+	hipStream_t st = current_stream();
+	residual(s, L, sx.get(), sb.get(), L.res, st);
+	const double res0 = l2_dev(s, L, L.res);
+	rel[0] = res0;
+	int it = 0;
+	for (it = 0; it < s->st.max_iter; it++) {
+		cycle_dev(s, sx.get(), sb.get());
+		residual(s, L, sx.get(), sb.get(), L.res, st);
+		const double r = l2_dev(s, L, L.res) / res0;
+		rel[it + 1] = r;
+		if (r < s->st.tol) { it++; break; }
+	}
+	return it;
+}
+
+float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n)
+{
+	hipStream_t st = current_stream();
+	hipEvent_t e0, e1;
+	CEDAR_HIP_CHECK(hipEventCreate(&e0));
+	CEDAR_HIP_CHECK(hipEventCreate(&e1));
+	CEDAR_HIP_CHECK(hipEventRecord(e0, st));
+	for (int i = 0; i < n; i++) cycle_dev(s, x_dev, b_dev);
+	CEDAR_HIP_CHECK(hipEventRecord(e1, st));
+	CEDAR_HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	CEDAR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	return ms;
+}
+
+float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n)
+{
+	hipStream_t st = current_stream();
+	const Level &L = s->lv[0];
+	hipEvent_t e0, e1;
+	CEDAR_HIP_CHECK(hipEventCreate(&e0));
+	CEDAR_HIP_CHECK(hipEventCreate(&e1));
+	CEDAR_HIP_CHECK(hipEventRecord(e0, st));
+	for (int i = 0; i < n; i++) smooth(s, L, x_dev, b_dev, (i & 1) ? BMG_UP : BMG_DOWN, 1, st);
+	CEDAR_HIP_CHECK(hipEventRecord(e1, st));
+	CEDAR_HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	CEDAR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	return ms;
+}
+
+} // extern "C"

@@ -9,6 +9,8 @@
 #include <map>
 #include <vector>
 
+extern "C" void print_error(char *msg); // host-overridable error callback (capi.cpp)
+
 namespace cedar_amd {
 
 hipStream_t current_stream();

@@ -1,0 +1,134 @@
+"""GPU parity of the device-resident multilevel solver (handle API of the C-ABI):
+hierarchy (A, P, SOR, ABD per level) and iteration-for-iteration residual norms
+against the golden histories of the reference's Fortran and against the oracle.
+
+Tolerance on histories: north_star's 1e-10 relative, with the rounding floor of
+r = b - A x as absolute tolerance (tests/cases.py HIST_ATOL; see test_oracle.py).
+"""
+import numpy as np
+import pytest
+
+import cases
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from cedar_amd import capi
+    assert capi.device_count() >= 1, "no GPU visible"
+    return capi
+
+
+@pytest.mark.parametrize("name", list(cases.SOLVES), ids=str)
+def test_solve_history_vs_reference_golden(capi, golden, name):
+    mk_op, mk_rhs, st = cases.SOLVES[name]
+    gold = golden["solves"][name]
+    so, b = mk_op(), mk_rhs()
+    s = capi.Solver(so, **st)
+    assert s.nlevels() == gold["nlevels"]
+    for l in range(s.nlevels()):
+        nx, ny, nz = s.dims(l)
+        want = gold["level_dims"][l]
+        assert [nx + 2, ny + 2, nz + 2][: len(want)] == want
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    s.close()
+    want = [float(gold["res0_l2"])] + [float(v) for v in gold["rel_l2"]]
+    assert len(h) == len(want)
+    np.testing.assert_allclose(h, want, rtol=1e-10, atol=cases.HIST_ATOL.get(name, 1e-14))
+
+
+@pytest.mark.parametrize("name", ["varcoef9_200x120_v21", "fe27_40x33x50_v21", "poisson7_64_v21",
+                                  "stretch5_800x200_linex", "poisson5_400_v11"], ids=str)
+def test_hierarchy_vs_oracle(capi, oracle, name):
+    """every level's operator, interpolation and relaxation data against the oracle's set-up"""
+    mk_op, _, st = cases.SOLVES[name]
+    so = mk_op()
+    s = capi.Solver(so, **st)
+    ml = oracle.ml_create(so, **st)
+    try:
+        assert s.nlevels() == ml.nlevels()
+        for l in range(s.nlevels()):
+            assert s.dims(l) == ml.dims(l)
+            for what in ("A", "P", "SOR0"):
+                a, w = s.array(l, what), ml.array(l, what)
+                if w is None:
+                    continue
+                if l == s.nlevels() - 1 and what == "SOR0":
+                    continue  # coarsest level has no relaxation set-up
+                scale = np.max(np.abs(w)) + 1e-300
+                assert np.max(np.abs(a - w)) <= 1e-12 * scale, (l, what, np.max(np.abs(a - w)) / scale)
+        a, w = s.array(0, "ABD"), ml.array(0, "ABD")
+        assert np.max(np.abs(a - w)) <= 1e-12 * np.max(np.abs(w))
+    finally:
+        s.close()
+        ml.close()
+
+
+def test_vcycle_device_resident_and_graph_replay(capi, oracle):
+    """cycle->run(x,b) on HBM-resident x,b (hipGraph replay) == oracle V-cycle, several cycles"""
+    so, b = pb.fe3(33, 30, 29), pb.rhs3(33, 30, 29)
+    s = capi.Solver(so)
+    ml = oracle.ml_create(so)
+    dx, db = capi.DeviceArray(b.shape), capi.DeviceArray.from_numpy(b)
+    x = np.zeros_like(b)
+    for _ in range(4):
+        s.vcycle(dx, db)
+        ml.vcycle(x, b)
+        got = dx.numpy()
+        assert np.max(np.abs(got - x)) <= 1e-12 * np.max(np.abs(x))
+    s.close()
+    ml.close()
+
+
+def test_reference_acceptance_2d(capi):
+    """test/2d/test_poisson.cc:64-93: 200^2, defaults: ||r||_2 < 1e-8 within 10 cycles, error < 1e-4"""
+    so, b = pb.poisson2(200, 200), pb.rhs2(200, 200)
+    s = capi.Solver(so)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    s.close()
+    assert h[-1] * h[0] < 1e-8
+    assert np.max(np.abs((pb.exact2(200, 200) - x)[1:-1, 1:-1])) < 1e-4
+
+
+def test_gallery_on_device_matches_reference_generators(capi):
+    """device-side gallery == numpy restatement of src/{2d,3d}/gallery.cc (bit-exact operators)"""
+    for name, n, ref in (("poisson2", (37, 20), pb.poisson2(37, 20)), ("fe2", (9, 13), pb.fe2(9, 13)),
+                         ("poisson3", (9, 10, 11), pb.poisson3(9, 10, 11)), ("fe3", (7, 8, 9), pb.fe3(7, 8, 9))):
+        so, b = capi.gallery(name, n)
+        assert np.array_equal(so.numpy(), ref), name
+    so, _ = capi.gallery("diag_diffusion2", (30, 12), params=(1.0, 1e-4), with_rhs=False)
+    assert np.array_equal(so.numpy(), pb.diag_diffusion2(30, 12, 1.0, 1e-4))
+    _, b = capi.gallery("poisson2", (40, 40))
+    np.testing.assert_allclose(b.numpy(), pb.rhs2(40, 40), rtol=1e-14, atol=1e-18)
+
+
+def test_round_trip_properties_at_benchmark_scale(capi):
+    """size-independent properties on a grid too large for goldens (256^3 27-pt, on device):
+    (1) linearity of the residual in x, (2) restrict is the transpose of interpolation:
+    <P^T r, e_c> = <r, P e_c>, (3) a relax sweep leaves ghost cells untouched."""
+    n = 192
+    so, b = capi.gallery("fe3", (n, n, n))
+    s = capi.Solver(so, share_operator=True)
+    K = capi.Kernels()
+    g = (n + 2,) * 3
+    x = capi.DeviceArray.from_numpy(pb.uniform(g, 11, -1, 1))
+    r1, r2 = capi.DeviceArray(g), capi.DeviceArray(g)
+    zero = capi.DeviceArray(g)
+    K.residual3(so, b, x, r1)       # b - A x
+    K.residual3(so, zero, x, r2)    # -A x
+    d = r1.numpy() - r2.numpy() - b.numpy()
+    assert np.max(np.abs(d[1:-1, 1:-1, 1:-1])) <= 1e-12
+    # ghost cells survive a sweep bit-for-bit
+    sor = capi.DeviceArray((2,) + g)
+    K.setup_recip3(so, sor)
+    x0 = x.numpy()
+    K.relax3(so, b, x, sor, 1)
+    x1 = x.numpy()
+    m = pb.interior_mask(g)
+    assert np.array_equal(x1[~m], x0[~m])
+    assert not np.array_equal(x1[m], x0[m])
+    s.close()
