@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fine-grid DOF/s per BoxMG V-cycle on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+One "step" = one V(2,1) cycle (`cycle->run(x,b)` of include/cedar/cycle/vcycle.h:57-115)
+on synthetic, HBM-resident data; set-up and the convergence-check residual are
+outside the timed region.  Prints ONE JSON line.
+
+Workloads (BASELINE.json configs; synthetic operators built on the device):
+  3d27   3D 27-pt gallery::fe,        512^3 per GPU, point 8-colour GS   (default; config 4 / 5,
+         the configuration the north-star roofline target is quoted on)
+  2d9    2D 9-pt variable coefficient, 4096^2, point 4-colour GS          (config 2)
+  2d9l   2D 9-pt anisotropic,          8192^2, zebra line relax x+y       (config 3)
+  2d5    2D 5-pt Poisson,              512^2                              (config 1)
+Extra keys in the JSON line:
+  roofline     dominant kernel (the level-0 relax sweep): algorithmic bytes per launch
+               / average launch duration measured live with HIP events on the library's stream
+  cpu_baseline the oracle (C restatement of the reference, kind "port") timed on one host
+               core on a bounded sample of the same workload
+Multi-GPU (N > 1): one rank per GPU under torch.distributed (RCCL); see DESIGN.md section 7.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (nd, default n, relax, algorithmic B/DOF of one level-0 relax sweep, launches per sweep, label)
+    "3d27": (3, 512, "point", 136.0, 4, "3D 27-pt gallery::fe Poisson-type, {n}^3, 8-colour GS V(2,1)"),
+    "2d9": (2, 4096, "point", 64.0, 2, "2D 9-pt variable-coefficient, {n}^2, 4-colour GS V(2,1)"),
+    "2d9l": (2, 8192, "line-xy", 128.0, 8, "2D 9-pt anisotropic eps=1e-4, {n}^2, zebra line relax x+y V(2,1)"),
+    "2d5": (2, 512, "point", 48.0, 2, "2D 5-pt Poisson, {n}^2, red-black GS V(2,1)"),
+}
+
+
+def build_problem(capi, wl, n):
+    """operator + rhs in HBM"""
+    import problems as pb
+    if wl == "3d27":
+        return capi.gallery("fe3", (n, n, n))
+    if wl == "2d5":
+        return capi.gallery("poisson2", (n, n))
+    if wl == "2d9":
+        so = pb.varcoef9(n, n)
+    else:
+        so = pb.aniso9(n, n)
+    b = pb.rhs2(n, n)
+    return capi.DeviceArray.from_numpy(so), capi.DeviceArray.from_numpy(b)
+
+
+def cpu_baseline(wl, relax):
+    """oracle on a bounded sample of the same workload, one host core"""
+    import problems as pb
+    from pyoracle import Oracle
+    O = Oracle()
+    if wl == "3d27":
+        n, so, b = 96, pb.fe3(96, 96, 96), pb.rhs3(96, 96, 96)
+        sample = "27-pt gallery::fe 96^3"
+    elif wl == "2d9":
+        n, so, b = 1024, pb.varcoef9(1024, 1024), pb.rhs2(1024, 1024)
+        sample = "9-pt variable-coefficient 1024^2"
+    elif wl == "2d9l":
+        n, so, b = 1024, pb.aniso9(1024, 1024), pb.rhs2(1024, 1024)
+        sample = "9-pt anisotropic 1024^2 line-xy"
+    else:
+        n, so, b = 512, pb.poisson2(512, 512), pb.rhs2(512, 512)
+        sample = "5-pt Poisson 512^2"
+    ml = O.ml_create(so, relax=relax)
+    x = np.zeros_like(b)
+    ml.vcycle(x, b)  # warm-up
+    dof = float(n) ** so.ndim if False else float(np.prod([s - 2 for s in b.shape]))
+    t0, cycles = time.perf_counter(), 0
+    while True:
+        ml.vcycle(x, b)
+        cycles += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or cycles >= 40:
+            break
+    ml.close()
+    return {"value": dof * cycles / dt, "unit": "DOF/s", "cores": 1, "kind": "port",
+            "sample": f"{sample}, {cycles} V(2,1) cycles, oracle/liboracle.so (gcc -O2, 1 thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="3d27", choices=list(WORKLOADS))
+    ap.add_argument("--size", type=int, default=0, help="override the per-GPU grid extent")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    nd, n_default, relax, bytes_per_dof, launches, label = WORKLOADS[args.workload]
+    n = args.size or n_default
+
+    from cedar_amd import capi
+    if capi.device_count() < 1:
+        raise SystemExit("bench.py: no GPU visible; cedar_amd has no CPU fallback")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    capi.set_device(local_rank)
+
+    so, b = build_problem(capi, args.workload, n)
+    solver = capi.Solver(so, relax=relax, share_operator=True)
+    x = capi.DeviceArray(b.shape)
+    dof = float(n) ** nd
+
+    def barrier():
+        capi.sync()
+        if dist is not None:
+            dist.barrier()
+            capi.sync()
+
+    for _ in range(args.warmup):
+        solver.vcycle(x, b)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.vcycle(x, b)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the level-0 relax sweep, HIP events on the library's stream
+    nsw = 20 if nd == 3 else 40
+    solver.time_relax(x, b, 4)
+    ms = solver.time_relax(x, b, nsw)
+    launch_ms = ms / (nsw * launches)
+    alg_bytes_launch = bytes_per_dof * dof / launches
+    achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        traffic = pmc.get(args.workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "relax sweep level 0 (%s)" % ("relax27_rows" if nd == 3 else relax),
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": traffic, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes_launch}
+
+    if rank == 0:
+        out = {
+            "metric": "fine-grid DOF/s per V-cycle",
+            "value": dof * world * args.steps / elapsed,
+            "unit": "DOF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": label.format(n=n) + (", %d GPUs" % world if world > 1 else ""),
+                       "grid_per_gpu": [n] * nd, "levels": solver.nlevels(), "cycle": "V(2,1)",
+                       "relaxation": relax,
+                       "parallelism": "single GPU" if world == 1 else "%d independent replicas (see DESIGN.md section 7)" % world},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, relax)
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
