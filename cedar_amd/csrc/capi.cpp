@@ -157,6 +157,8 @@ double cedar_amd_l2norm(const real_t *v, len_t II, len_t JJ, len_t KK)
 void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len_t nz, const double *params)
 {
 	static const int nst_of[13] = { 3, 3, 5, 0, 0, 0, 0, 0, 0, 0, 4, 4, 14 };
+	const int which_in = which;
+	if (which >= 100) which -= 100; /* placed inside a global grid, see gallery.hip */
 	if (which < 0 || which > 12 || nst_of[which] == 0) {
 		report("cedar_amd_gallery: unknown operator");
 		return;
@@ -167,7 +169,7 @@ void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len
 	Staged sb(b, npts, false, true);
 	CEDAR_HIP_CHECK(hipMemsetAsync(sso.get(), 0, npts * nst_of[which] * sizeof(real_t), current_stream()));
 	if (b) CEDAR_HIP_CHECK(hipMemsetAsync(sb.get(), 0, npts * sizeof(real_t), current_stream()));
-	gallery_fill(which, sso.get(), sb.get(), (int)nx, (int)ny, d3 ? (int)nz : 1, params, current_stream());
+	gallery_fill(which_in, sso.get(), sb.get(), (int)nx, (int)ny, d3 ? (int)nz : 1, params, current_stream());
 }
 
 // ------------------------------------------------------------------ 2D drop-ins
@@ -318,6 +320,40 @@ void BMG2_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, real_t *abd
 	size_t P = (size_t)ii * jj, NA = (size_t)nabd1 * nabd2;
 	Staged sq(q, P, true, true), sqf(qf, P, true, false), sabd(abd, NA, true, false), sb(bbd, nabd2, false, true);
 	solve_cg2(sq.get(), sqf.get(), (int)ii, (int)jj, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
+}
+
+// ------------------------------------------------------------------ domain-decomposition pieces
+void cedar_amd_relax3_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                           int jb, int kb, int efirst)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_pass27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, jb, kb, efirst, current_stream());
+}
+
+void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                            int icol, int jb, int kb)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_fixup27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, icol, jb, kb, current_stream());
+}
+
+void cedar_amd_relax3_colour7(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int pts)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 4, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_colour7(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, pts, current_stream());
+}
+
+void cedar_amd_setup_interp3_phase(real_t *so, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                   len_t iic, len_t jjc, len_t kkc, int ifd, int nstncl, int phase,
+                                   int ilo, int jlo, int klo)
+{
+	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
+	Staged sso(so, P * nstncl, true, false), sci(ci, PC * 26, true, true);
+	setup_interp3_phase(sso.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc, ifd,
+	                    phase, ilo, jlo, klo, current_stream());
 }
 
 // ------------------------------------------------------------------ 3D drop-ins

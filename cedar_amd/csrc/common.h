@@ -52,6 +52,12 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, size_t KK, hipStream_t st);
 void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int KK, int nstncl, int updown, hipStream_t st);
+void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st);
+void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    int II, int JJ, int KK, int icol, int jb, int kb, hipStream_t st);
+void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    int II, int JJ, int KK, int pts, hipStream_t st);
 // relax2d.hip
 void relax2_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int nstncl, int updown, hipStream_t st);
@@ -74,6 +80,8 @@ void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, con
 void setup_interp2(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, hipStream_t st);
 void setup_interp3(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,
                    int IIC, int JJC, int KKC, int ifd, hipStream_t st);
+void setup_interp3_phase(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,
+                         int IIC, int JJC, int KKC, int ifd, int phase, int ilo, int jlo, int klo, hipStream_t st);
 // galerkin.hip
 void galerkin2(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int IIC, int JJC,
                int ifd, hipStream_t st);

@@ -35,14 +35,17 @@ __global__ void gallery2_kernel(int which, real_t *__restrict__ so, real_t *__re
 }
 
 // which: 10 poisson3, 11 diag_diffusion3, 12 fe3
+// (gi0,gj0,gk0): offset of this subdomain inside the global grid, (gnx,gny,gnz): global extents;
+// a single-domain run has offsets 0 and global = local extents.
 __global__ void gallery3_kernel(int which, real_t *__restrict__ so, real_t *__restrict__ b, int nx, int ny, int nz,
-                                double dx, double dy, double dz)
+                                double dx, double dy, double dz, int gi0, int gj0, int gk0, int gnx, int gny, int gnz)
 {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1, k = blockIdx.z + 1;
-	if (i > nx) return;
+	const int li = blockIdx.x * blockDim.x + threadIdx.x + 1, lj = blockIdx.y + 1, lk = blockIdx.z + 1;
+	if (li > nx) return;
 	const int II = nx + 2, JJ = ny + 2, KK = nz + 2;
-	const size_t sk = (size_t)II * JJ, PS = sk * KK, x = (size_t)i + (size_t)II * j + sk * k;
-	const double hx = 1.0 / (II - 1), hy = 1.0 / (JJ - 1), hz = 1.0 / (KK - 1);
+	const size_t sk = (size_t)II * JJ, PS = sk * KK, x = (size_t)li + (size_t)II * lj + sk * lk;
+	const int i = li + gi0, j = lj + gj0, k = lk + gk0; // global 0-based-with-ghost index
+	const double hx = 1.0 / (gnx + 1), hy = 1.0 / (gny + 1), hz = 1.0 / (gnz + 1);
 	if (which == 12) {
 		if (i >= 2) so[KPW * PS + x] = 1.0;
 		if (j >= 2) so[KPS * PS + x] = 1.0;
@@ -68,16 +71,26 @@ __global__ void gallery3_kernel(int which, real_t *__restrict__ so, real_t *__re
 	}
 }
 
+// params: diag_diffusion: (dx,dy[,dz]).  `which` + 100 (e.g. 112 = fe3) places the subdomain
+// inside a global grid: (gi0,gj0,gk0,gnx,gny,gnz) follow the operator's own parameters
+// (3 for diag_diffusion3, else 0).
 void gallery_fill(int which, real_t *so, real_t *b, int nx, int ny, int nz, const double *params, hipStream_t st)
 {
 	double p0 = 1.0, p1 = 1.0, p2 = 1.0;
+	int off[6] = { 0, 0, 0, nx, ny, nz };
+	if (which >= 100) {
+		which -= 100;
+		const double *pp = params + (which == 11 ? 3 : 0);
+		for (int t = 0; t < 6; t++) off[t] = (int)pp[t];
+	}
 	if ((which == 1 || which == 11) && params) { p0 = params[0]; p1 = params[1]; if (which == 11) p2 = params[2]; }
 	if (which < 10) {
 		dim3 grid((nx + 255) / 256, ny);
 		hipLaunchKernelGGL(gallery2_kernel, grid, dim3(256), 0, st, which, so, b, nx, ny, p0, p1);
 	} else {
 		dim3 grid((nx + 127) / 128, ny, nz);
-		hipLaunchKernelGGL(gallery3_kernel, grid, dim3(128), 0, st, which, so, b, nx, ny, nz, p0, p1, p2);
+		hipLaunchKernelGGL(gallery3_kernel, grid, dim3(128), 0, st, which, so, b, nx, ny, nz, p0, p1, p2,
+		                   off[0], off[1], off[2], off[3], off[4], off[5]);
 	}
 }
 

@@ -304,6 +304,56 @@ static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t 
 		hipLaunchKernelGGL((relax27_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk);
 }
 
+// one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs
+// exchange halos between row classes)
+void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st)
+{
+	const int npairs = (II - 2 + 1) / 2;
+	if (npairs <= 64) launch_rows<64>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+	else if (npairs <= 128) launch_rows<128>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+	else if (npairs <= 256) launch_rows<256>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+	else if (npairs <= 512) launch_rows<512>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+	else {
+		for (int c = 0; c < 2; c++) {
+			int ib = efirst ? c : 1 - c;
+			int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+			if (ni <= 0 || nj <= 0 || nk <= 0) continue;
+			hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nk, 256)), dim3(256), 0, st,
+			                   so, qf, q, sor, II, JJ, KK, ib, jb, kb);
+		}
+	}
+}
+
+// recompute the points of column `icol` (0-based incl. ghost) in the rows of class (jb,kb):
+// used after a halo update of the neighbouring first-colour column (distributed runs)
+__global__ void relax27_column(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                               real_t *__restrict__ q, const real_t *__restrict__ sor,
+                               int II, int JJ, int KK, int icol, int jb, int kb)
+{
+	int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nj * nk) return;
+	size_t PS = (size_t)II * JJ * KK;
+	size_t x = (size_t)icol + (size_t)II * ((size_t)(1 + jb + 2 * (t % nj)) + (size_t)JJ * (size_t)(1 + kb + 2 * (t / nj)));
+	q[x] = offdiag27_mem(so, qf, q, II, JJ, PS, x) * sor[PS + x];
+}
+
+void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    int II, int JJ, int KK, int icol, int jb, int kb, hipStream_t st)
+{
+	int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	if (nj <= 0 || nk <= 0) return;
+	hipLaunchKernelGGL(relax27_column, dim3((nj * nk + 127) / 128), dim3(128), 0, st, so, qf, q, sor, II, JJ, KK, icol, jb, kb);
+}
+
+void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    int II, int JJ, int KK, int pts, hipStream_t st)
+{
+	size_t n = (size_t)((II - 2 + 1) / 2) * (JJ - 2) * (KK - 2);
+	hipLaunchKernelGGL(relax7_colour, dim3(cap_grid(n, 256)), dim3(256), 0, st, so, qf, q, sor, II, JJ, KK, pts);
+}
+
 void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int KK, int nstncl, int updown, hipStream_t st)
 {

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void interp2_edges(const real_t *__restrict__ 
         int IIF, int JJF, int IIC, int JJC, int ifd)
 {
 	const real_t zeps = DBL_EPSILON;
+	const int ilo = 3, jlo = 3; // serial bounds (2D has no distributed variant)
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2; // 1-based
 	const int IIC1 = IIC - 1, JJC1 = JJC - 1;
 	const int IICF1 = (IIF - 2) / 2 + 2, JJCF1 = (JJF - 2) / 2 + 2;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void interp2_edges(const real_t *__restrict__ 
 	const int i = 2 * (ic - 1), j = 2 * (jc - 1);
 	real_t a, b, ep, sum, s;
 	(void)a; (void)b; (void)s;
-	if (ic >= 3 && ic <= IICF1 && jc >= 2 && jc <= JJC1) {
+	if (ic >= ilo && ic <= IICF1 && jc >= 2 && jc <= JJC1) {
 
 	if (ifd != 1) {
 		a = SO(i, j, KW) + SO(i, j, KNW) + SO(i, j + 1, KSW);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void interp2_edges(const real_t *__restrict__ 
 	CIW(ic, jc, LR) = a * sum;
 	CIW(ic, jc, LL) = b * sum;
 	}
-	if (ic >= 2 && ic <= IIC1 && jc >= 3 && jc <= JJCF1) {
+	if (ic >= 2 && ic <= IIC1 && jc >= jlo && jc <= JJCF1) {
 
 	if (ifd != 1) {
 		a = SO(i, j, KS) + SO(i, j, KNW) + SO(i + 1, j, KSW);
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void interp2_centres(const real_t *__restrict_
         int IIF, int JJF, int IIC, int JJC, int ifd)
 {
 	const real_t zeps = DBL_EPSILON;
+	const int ilo = 3, jlo = 3; // serial bounds (2D has no distributed variant)
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2; // 1-based
 	const int IIC1 = IIC - 1, JJC1 = JJC - 1;
 	const int IICF1 = (IIF - 2) / 2 + 2, JJCF1 = (JJF - 2) / 2 + 2;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void interp2_centres(const real_t *__restrict_
 	const int i = 2 * (ic - 1), j = 2 * (jc - 1);
 	real_t a, b, ep, sum, s;
 	(void)a; (void)b; (void)s;
-	if (ic >= 3 && ic <= IICF1 && jc >= 3 && jc <= JJCF1) {
+	if (ic >= ilo && ic <= IICF1 && jc >= jlo && jc <= JJCF1) {
 
 	real_t d = SO(i - 1, j - 1, KO);
 	if (ifd != 1) {
@@ -150,7 +152,7 @@ void setup_interp2(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int 
 #define CW(ic, jc, kc, s) ci[(size_t)((ic)-1) + (size_t)IIC * ((size_t)((jc)-1) + (size_t)JJC * ((size_t)((kc)-1) + (size_t)KKC * (size_t)(s)))]
 
 __global__ __launch_bounds__(128) void interp3_edges(const real_t *__restrict__ so, real_t *ci,
-        int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd)
+        int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd, int ilo, int jlo, int klo)
 {
 	const real_t eMACH = 1.e-13;
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2, kc = blockIdx.z + 2; // 1-based
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(128) void interp3_edges(const real_t *__restrict__ 
 	real_t a, b, c, ep, dnw, dn, dne, dw, de, dsw, ds, dse, dp, sum;
 	(void)a; (void)b; (void)c; (void)ep; (void)dnw; (void)dn; (void)dne; (void)dw; (void)de;
 	(void)dsw; (void)ds; (void)dse; (void)dp; (void)sum;
-	if (kc <= kkc1 && jc <= jjc1 && ic >= 3 && ic <= iicf1) {
+	if (kc <= kkc1 && jc <= jjc1 && ic >= ilo && ic <= iicf1) {
 
 	real_t d = SO(i - 1, j, k, KP);
 	if (ifd != 1) {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(128) void interp3_edges(const real_t *__restrict__ 
 	CW(ic, jc, kc, LXYL) = a / c;
 	CW(ic, jc, kc, LXYR) = b / c;
 	}
-	if (kc <= kkc1 && jc >= 3 && jc <= jjcf1 && ic <= iic1) {
+	if (kc <= kkc1 && jc >= jlo && jc <= jjcf1 && ic <= iic1) {
 
 	real_t d = SO(i, j - 1, k, KP);
 	if (ifd != 1) {
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(128) void interp3_edges(const real_t *__restrict__ 
 	CW(ic, jc, kc, LXYA) = a / c;
 	CW(ic, jc, kc, LXYB) = b / c;
 	}
-	if (kc >= 3 && kc <= kkcf1 && jc <= jjc1 && ic <= iic1) {
+	if (kc >= klo && kc <= kkcf1 && jc <= jjc1 && ic <= iic1) {
 
 	real_t d = SO(i, j, k - 1, KP);
 	if (ifd != 1) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(128) void interp3_edges(const real_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(128) void interp3_faces(const real_t *__restrict__ so, real_t *ci,
-        int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd)
+        int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd, int ilo, int jlo, int klo)
 {
 	const real_t eMACH = 1.e-13;
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2, kc = blockIdx.z + 2; // 1-based
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(128) void interp3_faces(const real_t *__restrict__ 
 	real_t a, b, c, ep, dnw, dn, dne, dw, de, dsw, ds, dse, dp, sum;
 	(void)a; (void)b; (void)c; (void)ep; (void)dnw; (void)dn; (void)dne; (void)dw; (void)de;
 	(void)dsw; (void)ds; (void)dse; (void)dp; (void)sum;
-	if (kc <= kkc1 && jc >= 3 && jc <= jjcf1 && ic >= 3 && ic <= iicf1) {
+	if (kc <= kkc1 && jc >= jlo && jc <= jjcf1 && ic >= ilo && ic <= iicf1) {
 
 	real_t d = SO(i - 1, j - 1, k, KP);
 	if (ifd != 1) {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(128) void interp3_faces(const real_t *__restrict__ 
 		                              + CW(ic - 1, jc, kc, LXYB) * dw);
 	}
 	}
-	if (kc >= 3 && kc <= kkcf1 && jc <= jjc1 && ic >= 3 && ic <= iicf1) {
+	if (kc >= klo && kc <= kkcf1 && jc <= jjc1 && ic >= ilo && ic <= iicf1) {
 
 	real_t d = SO(i - 1, j, k - 1, KP);
 	if (ifd != 1) {
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(128) void interp3_faces(const real_t *__restrict__ 
 		                              + CW(ic - 1, jc, kc, LXZB) * dw);
 	}
 	}
-	if (kc >= 3 && kc <= kkcf1 && jc >= 3 && jc <= jjcf1 && ic <= iic1) {
+	if (kc >= klo && kc <= kkcf1 && jc >= jlo && jc <= jjcf1 && ic <= iic1) {
 
 	real_t d = SO(i, j - 1, k - 1, KP);
 	if (ifd != 1) {
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(128) void interp3_faces(const real_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(128) void interp3_centres(const real_t *__restrict__ so, real_t *ci,
-        int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd)
+        int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd, int ilo, int jlo, int klo)
 {
 	const real_t eMACH = 1.e-13;
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2, kc = blockIdx.z + 2; // 1-based
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(128) void interp3_centres(const real_t *__restrict_
 	real_t a, b, c, ep, dnw, dn, dne, dw, de, dsw, ds, dse, dp, sum;
 	(void)a; (void)b; (void)c; (void)ep; (void)dnw; (void)dn; (void)dne; (void)dw; (void)de;
 	(void)dsw; (void)ds; (void)dse; (void)dp; (void)sum;
-	if (kc >= 3 && kc <= kkcf1 && jc >= 3 && jc <= jjcf1 && ic >= 3 && ic <= iicf1) {
+	if (kc >= klo && kc <= kkcf1 && jc >= jlo && jc <= jjcf1 && ic >= ilo && ic <= iicf1) {
 
 	real_t d = SO(i - 1, j - 1, k - 1, KP);
 	real_t yp, yw;
@@ -625,14 +627,28 @@ __global__ __launch_bounds__(128) void interp3_centres(const real_t *__restrict_
 	}
 }
 
-void setup_interp3(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,
-                   int IIC, int JJC, int KKC, int ifd, hipStream_t st)
+// phase 0 = edges, 1 = faces, 2 = cell centres.  (ilo,jlo,klo) are the lower loop bounds of
+// the "between two coarse points" directions: 3 in the reference's serial code; 2 on a side
+// where a neighbouring subdomain owns the previous coarse point (distributed runs; the fine
+// and coarse ghost layers then hold that neighbour's data).
+void setup_interp3_phase(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,
+                         int IIC, int JJC, int KKC, int ifd, int phase, int ilo, int jlo, int klo, hipStream_t st)
 {
 	if (IIC < 2 || JJC < 2 || KKC < 2) return;
 	dim3 grid((IIC - 1 + 127) / 128, JJC - 1, KKC - 1); // ic,jc,kc in [2,IIC] x [2,JJC] x [2,KKC]
-	hipLaunchKernelGGL(interp3_edges, grid, dim3(128), 0, st, so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd);
-	hipLaunchKernelGGL(interp3_faces, grid, dim3(128), 0, st, so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd);
-	hipLaunchKernelGGL(interp3_centres, grid, dim3(128), 0, st, so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd);
+	if (phase == 0)
+		hipLaunchKernelGGL(interp3_edges, grid, dim3(128), 0, st, so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, ilo, jlo, klo);
+	else if (phase == 1)
+		hipLaunchKernelGGL(interp3_faces, grid, dim3(128), 0, st, so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, ilo, jlo, klo);
+	else
+		hipLaunchKernelGGL(interp3_centres, grid, dim3(128), 0, st, so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, ilo, jlo, klo);
+}
+
+void setup_interp3(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,
+                   int IIC, int JJC, int KKC, int ifd, hipStream_t st)
+{
+	for (int phase = 0; phase < 3; phase++)
+		setup_interp3_phase(so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, phase, 3, 3, 3, st);
 }
 #undef SO
 #undef CW

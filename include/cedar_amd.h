@@ -130,6 +130,28 @@ double cedar_amd_l2norm(const real_t *v, len_t II, len_t JJ, len_t KK);
 void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len_t nz,
                        const double *params);
 
+/* ------------------------------------------------------------------ 1b. pieces for domain-decomposed runs
+ * The MPI flavour of the reference interleaves halo exchanges with the colours of a sweep and
+ * with the phases of the interpolation set-up (src/3d/ftn/mpi/BMG3_SymStd_relax_GS.f90:102-147,
+ * src/3d/ftn/mpi/BMG3_SymStd_SETUP_interp_OI.f90:418-1074).  These entry points expose the same
+ * granularity so that a host (cedar_amd/dist.py) can place RCCL exchanges between them.
+ * Arrays: host or device, local subdomain incl. one ghost layer, Cedar layout. */
+/* one row class (jb,kb in {0,1}: parity of 1-based j,k minus 2) of the 27-point sweep: both i-colours,
+ * efirst != 0: even 1-based i first (the UP order) */
+void cedar_amd_relax3_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                           int jb, int kb, int efirst);
+/* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
+void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                            int icol, int jb, int kb);
+/* one colour of the 7-point red-black sweep (pts = 0|1, BMG3_SymStd_relax_GS.f90:155-184) */
+void cedar_amd_relax3_colour7(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                              int pts);
+/* one phase (0 edges, 1 faces, 2 centres) of BMG3_SymStd_SETUP_interp_OI with lower loop bounds
+ * ilo,jlo,klo (3 = serial / physical boundary, 2 = a neighbouring subdomain owns coarse point 1) */
+void cedar_amd_setup_interp3_phase(real_t *so, real_t *ci, len_t iif, len_t jjf, len_t kkf,
+                                   len_t iic, len_t jjc, len_t kkc, int ifd, int nstncl, int phase,
+                                   int ilo, int jlo, int klo);
+
 /* ------------------------------------------------------------------ 2. handle API */
 typedef struct cedar_amd_solver cedar_amd_solver;
 

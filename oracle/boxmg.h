@@ -76,6 +76,12 @@ int orc2_solve_cg(real_t *q, const real_t *qf, len_t II, len_t JJ,
 void orc3_setup_recip(const real_t *so, real_t *sor, len_t II, len_t JJ, len_t KK);
 void orc3_relax_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                    len_t II, len_t JJ, len_t KK, int ifd, int updown);
+void orc3_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, len_t KK, int ifd, int pts);
+void orc3_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, len_t KK, int i, int jb, int kb);
+void orc3_setup_interp_ex(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
+                          len_t IIC, len_t JJC, len_t KKC, int ifd, int phase_mask, int ilo, int jlo, int klo);
 void orc3_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                    len_t II, len_t JJ, len_t KK, int ifd);
 void orc3_restrict(const real_t *q, real_t *qc, const real_t *ci,

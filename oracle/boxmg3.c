@@ -96,6 +96,35 @@ void orc3_relax_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	}
 }
 
+/* one colour of the sweep (27-pt: pts 1..8; 7-pt: pts 0..1): what the MPI flavour runs between
+ * two halo exchanges (src/3d/ftn/mpi/BMG3_SymStd_relax_GS.f90:102-147) */
+void orc3_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, len_t KK, int ifd, int pts)
+{
+	int I1 = (int)II - 1, J1 = (int)JJ - 1, K1 = (int)KK - 1;
+	if (ifd != 1) {
+		for (int k = 2 + ((pts - 1) / 4) % 2; k <= K1; k += 2)
+			for (int j = 2 + ((pts - 1) / 2) % 2; j <= J1; j += 2)
+				for (int i = 2 + (pts - 1) % 2; i <= I1; i += 2)
+					Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+	} else {
+		for (int k = 2; k <= K1; k++)
+			for (int j = 2; j <= J1; j++)
+				for (int i = (j + k + pts) % 2 + 2; i <= I1; i += 2)
+					Q(i, j, k) = OFFDIAG7(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+	}
+}
+
+/* recompute the 27-pt points of 1-based column i in the rows of class (jb,kb) */
+void orc3_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, len_t KK, int i, int jb, int kb)
+{
+	int J1 = (int)JJ - 1, K1 = (int)KK - 1;
+	for (int k = 2 + kb; k <= K1; k += 2)
+		for (int j = 2 + jb; j <= J1; j += 2)
+			Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+}
+
 /* src/3d/ftn/BMG3_SymStd_residual.f90:67-121 */
 void orc3_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                    len_t II, len_t JJ, len_t KK, int ifd)
@@ -306,8 +335,8 @@ static inline real_t min4(real_t a, real_t b, real_t c, real_t d) { return rmin(
 /* src/3d/ftn/BMG3_SymStd_SETUP_interp_OI.f90:120-538 (27-pt), :539-807 (7-pt);
  * non-periodic.  eMACH = 1e-13 (:78).  The reference's scratch yo() only holds
  * two scalars per point in the last phase; locals are used instead. */
-void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
-                       len_t IIC, len_t JJC, len_t KKC, int ifd)
+void orc3_setup_interp_ex(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
+                          len_t IIC, len_t JJC, len_t KKC, int ifd, int phase_mask, int ilo, int jlo, int klo)
 {
 #define SO(i, j, k, s) S3(so, IIF, JJF, KKF, i, j, k, s)
 #define CW(ic, jc, kc, s) S3(ci, IIC, JJC, KKC, ic, jc, kc, s)
@@ -317,11 +346,12 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 	real_t a, b, c, ep, dnw, dn, dne, dw, de, dsw, ds, dse, dp, sum;
 
 	/* (1) x-edges on coarse k-planes, coarse rows (:133-161 / :548-566) */
+	if (phase_mask & 1)
 	for (int kc = 2; kc <= kkc1; kc++) {
 		int k = 2 * (kc - 1);
 		for (int jc = 2; jc <= jjc1; jc++) {
 			int j = 2 * (jc - 1);
-			for (int ic = 3; ic <= iicf1; ic++) {
+			for (int ic = ilo; ic <= iicf1; ic++) {
 				int i = 2 * (ic - 1);
 				real_t d = SO(i - 1, j, k, KP);
 				if (ifd != 1) {
@@ -354,9 +384,10 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 		}
 	}
 	/* (2) y-edges on coarse k-planes (:166-196 / :571-589) */
+	if (phase_mask & 1)
 	for (int kc = 2; kc <= kkc1; kc++) {
 		int k = 2 * (kc - 1);
-		for (int jc = 3; jc <= jjcf1; jc++) {
+		for (int jc = jlo; jc <= jjcf1; jc++) {
 			int j = 2 * (jc - 1);
 			for (int ic = 2; ic <= iic1; ic++) {
 				int i = 2 * (ic - 1);
@@ -391,7 +422,8 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 		}
 	}
 	/* (3) z-edges (:201-229 / :594-612) */
-	for (int kc = 3; kc <= kkcf1; kc++) {
+	if (phase_mask & 1)
+	for (int kc = klo; kc <= kkcf1; kc++) {
 		int k = 2 * (kc - 1);
 		for (int jc = 2; jc <= jjc1; jc++) {
 			int j = 2 * (jc - 1);
@@ -426,11 +458,12 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 		}
 	}
 	/* (4) xy-face centres on coarse k-planes (:235-281 / :618-650) */
+	if (phase_mask & 2)
 	for (int kc = 2; kc <= kkc1; kc++) {
 		int k = 2 * (kc - 1);
-		for (int jc = 3; jc <= jjcf1; jc++) {
+		for (int jc = jlo; jc <= jjcf1; jc++) {
 			int j = 2 * (jc - 1);
-			for (int ic = 3; ic <= iicf1; ic++) {
+			for (int ic = ilo; ic <= iicf1; ic++) {
 				int i = 2 * (ic - 1);
 				real_t d = SO(i - 1, j - 1, k, KP);
 				if (ifd != 1) {
@@ -487,11 +520,12 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 		}
 	}
 	/* (5) xz-face centres on coarse j-planes (:287-332 / :656-688) */
-	for (int kc = 3; kc <= kkcf1; kc++) {
+	if (phase_mask & 2)
+	for (int kc = klo; kc <= kkcf1; kc++) {
 		int k = 2 * (kc - 1);
 		for (int jc = 2; jc <= jjc1; jc++) {
 			int j = 2 * (jc - 1);
-			for (int ic = 3; ic <= iicf1; ic++) {
+			for (int ic = ilo; ic <= iicf1; ic++) {
 				int i = 2 * (ic - 1);
 				real_t d = SO(i - 1, j, k - 1, KP);
 				if (ifd != 1) {
@@ -547,9 +581,10 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 		}
 	}
 	/* (6) yz-face centres on coarse i-planes (:338-381 / :694-726) */
-	for (int kc = 3; kc <= kkcf1; kc++) {
+	if (phase_mask & 2)
+	for (int kc = klo; kc <= kkcf1; kc++) {
 		int k = 2 * (kc - 1);
-		for (int jc = 3; jc <= jjcf1; jc++) {
+		for (int jc = jlo; jc <= jjcf1; jc++) {
 			int j = 2 * (jc - 1);
 			for (int ic = 2; ic <= iic1; ic++) {
 				int i = 2 * (ic - 1);
@@ -610,11 +645,12 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 	 * restated exactly as written in the reference, including the two terms
 	 * that are not divided by the diagonal and the repeated kbse entry
 	 * (:409-441). */
-	for (int kc = 3; kc <= kkcf1; kc++) {
+	if (phase_mask & 4)
+	for (int kc = klo; kc <= kkcf1; kc++) {
 		int k = 2 * (kc - 1);
-		for (int jc = 3; jc <= jjcf1; jc++) {
+		for (int jc = jlo; jc <= jjcf1; jc++) {
 			int j = 2 * (jc - 1);
-			for (int ic = 3; ic <= iicf1; ic++) {
+			for (int ic = ilo; ic <= iicf1; ic++) {
 				int i = 2 * (ic - 1);
 				real_t d = SO(i - 1, j - 1, k - 1, KP);
 				real_t yp, yw;
@@ -801,6 +837,14 @@ void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t
 	}
 #undef CW
 #undef SO
+}
+
+
+/* serial entry point: all phases, the reference's loop bounds (src/3d/ftn/BMG3_SymStd_SETUP_interp_OI.f90) */
+void orc3_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
+                       len_t IIC, len_t JJC, len_t KKC, int ifd)
+{
+	orc3_setup_interp_ex(so, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, 7, 3, 3, 3);
 }
 
 /* ------------------------------------------------------------------------

@@ -111,6 +111,20 @@ class Oracle:
         nst, KK, JJ, II = so.shape
         self.L.orc3_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), updown)
 
+    def relax_colour3(self, so, qf, q, sor, pts):
+        nst, KK, JJ, II = so.shape
+        self.L.orc3_relax_colour(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), pts)
+
+    def relax_column3(self, so, qf, q, sor, i1, jb, kb):
+        nst, KK, JJ, II = so.shape
+        self.L.orc3_relax_column(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), i1, jb, kb)
+
+    def setup_interp3_ex(self, so, ci, phase_mask, lo):
+        nst, KK, JJ, II = so.shape
+        _, KKC, JJC, IIC = ci.shape
+        self.L.orc3_setup_interp_ex(_p(so), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4),
+                                    phase_mask, lo[0], lo[1], lo[2])
+
     def residual3(self, so, qf, q, res):
         nst, KK, JJ, II = so.shape
         self.L.orc3_residual(_p(so), _p(qf), _p(q), _p(res), u(II), u(JJ), u(KK), int(nst == 4))

@@ -1,0 +1,64 @@
+"""TEST INFRASTRUCTURE: CPU backend for cedar_amd.dist.DistSolver3 built on the oracle, so that
+the distributed orchestration (topology, halo plans, pass sequencing, coarse gather) runs under
+gloo on CPU.  Mirrors cedar_amd.dist.GpuBackend method for method."""
+import numpy as np
+import torch
+
+from pyoracle import Oracle
+
+
+class CpuBackend:
+    def __init__(self):
+        self.O = Oracle()
+        self.device = torch.device("cpu")
+
+    @staticmethod
+    def _n(t):
+        a = t.numpy()
+        assert a.flags["C_CONTIGUOUS"]
+        return a
+
+    def zeros(self, shape):
+        return torch.zeros(shape, dtype=torch.float64)
+
+    def relax_pass(self, A, b, x, sor, jb, kb, efirst):
+        # the fused device kernel = the two i-colours of the row class back to back, no exchange between
+        for ib in ((0, 1) if efirst else (1, 0)):
+            self.O.relax_colour3(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb)
+
+    def relax_fixup(self, A, b, x, sor, icol, jb, kb):
+        self.O.relax_column3(self._n(A), self._n(b), self._n(x), self._n(sor), icol + 1, jb, kb)
+
+    def relax_colour7(self, A, b, x, sor, pts):
+        self.O.relax_colour3(self._n(A), self._n(b), self._n(x), self._n(sor), pts)
+
+    def recip(self, A, sor):
+        self.O.setup_recip3(self._n(A), self._n(sor))
+
+    def residual(self, A, x, b, r):
+        self.O.residual3(self._n(A), self._n(b), self._n(x), self._n(r))
+
+    def restrict(self, r, bc, P):
+        self.O.restrict3(self._n(r), self._n(bc), self._n(P))
+
+    def interp_add(self, x, xc, A, r, P):
+        self.O.interp_add3(self._n(x), self._n(xc), self._n(A), self._n(r), self._n(P))
+
+    def interp_phase(self, A, P, phase, lo):
+        self.O.setup_interp3_ex(self._n(A), self._n(P), 1 << phase, lo)
+
+    def galerkin(self, A, Ac, P):
+        self.O.galerkin3(self._n(A), self._n(Ac), self._n(P))
+
+    def setup_cg(self, A, abd):
+        self.O.setup_cg3(self._n(A), self._n(abd))
+
+    def solve_cg(self, x, b, abd, bbd):
+        self.O.solve_cg3(self._n(x), self._n(b), self._n(abd))
+
+    def sumsq(self, r):
+        v = self.O.l2(self._n(r))
+        return v * v
+
+    def sync(self):
+        pass
