@@ -106,6 +106,10 @@ def main():
     nd, n_default, relax, bytes_per_dof, launches, label = WORKLOADS[args.workload]
     n = args.size or n_default
 
+    if world > 1:
+        # torch bundles its own HIP runtime: it must be the first one loaded in a process that uses
+        # both torch.distributed and libcedar_amd.so, so that there is exactly one runtime
+        import torch  # noqa: F401
     from cedar_amd import capi
     if capi.device_count() < 1:
         raise SystemExit("bench.py: no GPU visible; cedar_amd has no CPU fallback")
@@ -114,14 +118,60 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)  # rehearsal on a one-GPU box: ranks share the card
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CEDAR_AMD_DIST_BACKEND", "nccl")  # "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     capi.set_device(local_rank)
 
-    so, b = build_problem(capi, args.workload, n)
-    solver = capi.Solver(so, relax=relax, share_operator=True)
-    x = capi.DeviceArray(b.shape)
     dof = float(n) ** nd
+    dsolver = None
+    if world > 1:
+        # domain decomposition: one 512^3 block per GPU of a (px,py,pz)*512 global grid, halo over RCCL
+        if args.workload != "3d27":
+            raise SystemExit("bench.py: multi-GPU runs are defined for the 3D 27-pt workload (BASELINE config 5)")
+        import torch
+        from cedar_amd.dist import DistSolver3, GpuBackend, Topology
+        dev = torch.device("cuda", local_rank)
+        topo = Topology(rank, world)
+        g = (n + 2, n + 2, n + 2)
+        A = torch.zeros((14,) + g, dtype=torch.float64, device=dev)
+        bt = torch.zeros(g, dtype=torch.float64, device=dev)
+        import ctypes as C
+        place = [float(topo.coord[d] * n) for d in range(3)] + [float(n * topo.p[d]) for d in range(3)]
+        pp = (C.c_double * 6)(*place)
+        capi.lib.cedar_amd_gallery(112, A.data_ptr(), bt.data_ptr(), n, n, n, pp)  # fe3 placed in the global grid
+        dsolver = DistSolver3(GpuBackend(dev), topo, A)
+        xt = torch.zeros_like(bt)
+        so = b = x = None
+
+        class _S:  # minimal adapter so that the timing code below is shared
+            def vcycle(self, x_, b_):
+                dsolver.vcycle(xt, bt)
+
+            def nlevels(self):
+                return len(dsolver.levels)
+
+            def time_relax(self, x_, b_, k):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for i in range(k):
+                    dsolver._smooth(dsolver.levels[0], xt, bt, i & 1, 1)
+                ev1.record()
+                ev1.synchronize()
+                return ev0.elapsed_time(ev1)
+
+            def close(self):
+                pass
+        solver = _S()
+    else:
+        so, b = build_problem(capi, args.workload, n)
+        solver = capi.Solver(so, relax=relax, share_operator=True)
+        x = capi.DeviceArray(b.shape)
 
     def barrier():
         capi.sync()
@@ -139,7 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -177,7 +227,8 @@ def main():
             "config": {"workload": label.format(n=n) + (", %d GPUs" % world if world > 1 else ""),
                        "grid_per_gpu": [n] * nd, "levels": solver.nlevels(), "cycle": "V(2,1)",
                        "relaxation": relax,
-                       "parallelism": "single GPU" if world == 1 else "%d independent replicas (see DESIGN.md section 7)" % world},
+                       "parallelism": "single GPU" if world == 1 else
+                       "domain decomposition %s ranks, %d^3 per GPU, halo exchange over RCCL" % ("x".join(map(str, topo.p)), n)},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,83 @@
+"""GPU multi-rank test runnable on the one-GPU box: 2 ranks share cuda:0, gloo transport (RCCL
+refuses two ranks on one device), HIP kernels through the C ABI.  Same criterion as
+tests/test_dist_cpu.py: the decomposed run reproduces the single-domain history."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, pgrid, outdir):
+    for p in (HERE, ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import problems as pb
+        from cedar_amd.dist import DistSolver3, GpuBackend, Topology
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        topo = Topology(rank, world, pgrid)
+        gn = tuple(n[d] * topo.p[d] for d in range(3))
+        g = (gn[2] + 2, gn[1] + 2, gn[0] + 2)
+        gso = pb.random_op(g, 14, 77)
+        gb = pb.uniform(g, 78, -1, 1) * pb.interior_mask(g)
+        ci, cj, ck = topo.coord
+        sl = (slice(ck * n[2], ck * n[2] + n[2] + 2), slice(cj * n[1], cj * n[1] + n[1] + 2),
+              slice(ci * n[0], ci * n[0] + n[0] + 2))
+        m = pb.interior_mask(tuple(s.stop - s.start for s in sl)).astype(np.float64)
+        A = torch.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m).to(dev)
+        b = torch.from_numpy(np.ascontiguousarray(gb[sl]) * m).to(dev)
+        x = torch.zeros_like(b)
+        s = DistSolver3(GpuBackend(dev), topo, A, max_iter=5)
+        h = s.solve(b, x)
+        np.save(os.path.join(outdir, f"x{rank}.npy"), x.cpu().numpy())
+        if rank == 0:
+            np.save(os.path.join(outdir, "hist.npy"), np.array(h))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,pgrid", [((16, 12, 10), (2, 1, 1)), ((8, 8, 8), (2, 2, 1))],
+                         ids=["2ranks", "4ranks"])
+def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, tmp_path, oracle):
+    import problems as pb
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    mp.spawn(_worker, args=(world, _free_port(), n, pgrid, str(tmp_path)), nprocs=world, join=True)
+    gn = tuple(n[d] * pgrid[d] for d in range(3))
+    g = (gn[2] + 2, gn[1] + 2, gn[0] + 2)
+    gso = pb.random_op(g, 14, 77)
+    gb = pb.uniform(g, 78, -1, 1) * pb.interior_mask(g)
+    ml = oracle.ml_create(gso)
+    x = np.zeros_like(gb)
+    want = ml.solve(gb, x, maxiter=5)
+    ml.close()
+    got = np.load(tmp_path / "hist.npy")
+    assert len(got) == len(want)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-14)
+    px, py, pz = pgrid
+    for r in range(world):
+        ci, cj, ck = r % px, (r // px) % py, r // (px * py)
+        xr = np.load(tmp_path / f"x{r}.npy")
+        ref = x[ck * n[2]:ck * n[2] + n[2] + 2, cj * n[1]:cj * n[1] + n[1] + 2, ci * n[0]:ci * n[0] + n[0] + 2]
+        own = (slice(1, -1),) * 3
+        assert np.max(np.abs(xr[own] - ref[own])) <= 1e-12 * np.max(np.abs(x))
