@@ -6,10 +6,10 @@
 // LAPACK they call (DPBTRF/DPBTRS, UPLO='U'; system LAPACK in the reference, not
 // vendored).  The coarsest grid holds a few dozen unknowns (16 in 2D, 64 in 3D
 // for every configuration here), far below DPBTRF's blocking threshold, so the
-// published unblocked DPBTF2 / DTBSV recurrences are restated and run by ONE
-// lane in their sequential order: latency ~10 us per V-cycle, negligible
-// against the fine-level sweeps, and it keeps the solve on the device (no PCIe
-// round trip inside the cycle).  The band is packed by the whole workgroup.
+// published unblocked DPBTF2 / DTBSV recurrences are restated.  The factorisation
+// (set-up, once) runs on one lane in sequential order; the solve (every cycle) runs
+// on one wavefront out of LDS (~10 us), on the device: no PCIe round trip inside
+// the cycle.  The band is packed by the whole workgroup.
 #include "common.h"
 
 namespace cedar_amd {
@@ -44,26 +44,52 @@ __device__ int dpbtf2_upper(int n, int kd, real_t *ab, int ldab)
 	return 0;
 }
 
-// DPBTRS 'U', one right-hand side: DTBSV('U','T','N') then DTBSV('U','N','N')
-__device__ void dpbtrs_upper(int n, int kd, const real_t *ab, int ldab, real_t *b)
+// DPBTRS 'U', one right-hand side = DTBSV('U','T','N') then DTBSV('U','N','N'), run by one
+// wavefront with the band factor and the right-hand side in LDS.  Row-oriented forward sweep /
+// column-oriented backward sweep: every b_i receives exactly the same subtractions in the same
+// order as in the sequential DTBSV loops, so the result is bit-identical to them; the lanes
+// only parallelise the independent updates of one elimination step.
+__device__ void dpbtrs_upper_wave(int n, int kd, const real_t *ab, int ldab, real_t *b)
 {
-	const int kp1 = kd + 1;
-	for (int j = 1; j <= n; j++) {
-		real_t temp = b[j - 1];
-		const int l = kp1 - j;
-		const int i0 = j - kd > 1 ? j - kd : 1;
-		for (int i = i0; i <= j - 1; i++) temp = temp - ab[(size_t)(l + i - 1) + (size_t)ldab * (size_t)(j - 1)] * b[i - 1];
-		temp = temp / ab[(size_t)kd + (size_t)ldab * (size_t)(j - 1)];
-		b[j - 1] = temp;
+	const int lane = threadIdx.x;
+	for (int j = 0; j < n; j++) {
+		if (lane == 0) b[j] = b[j] / ab[(size_t)kd + (size_t)ldab * j];
+		__syncthreads();
+		const real_t yj = b[j];
+		const int hi = j + kd < n - 1 ? j + kd : n - 1;
+		for (int i = j + 1 + lane; i <= hi; i += blockDim.x) b[i] = b[i] - ab[(size_t)(kd + j - i) + (size_t)ldab * i] * yj;
+		__syncthreads();
 	}
-	for (int j = n; j >= 1; j--) {
-		if (b[j - 1] != 0.0) {
-			const int l = kp1 - j;
-			b[j - 1] = b[j - 1] / ab[(size_t)kd + (size_t)ldab * (size_t)(j - 1)];
-			const real_t temp = b[j - 1];
-			const int i0 = j - kd > 1 ? j - kd : 1;
-			for (int i = j - 1; i >= i0; i--) b[i - 1] = b[i - 1] - temp * ab[(size_t)(l + i - 1) + (size_t)ldab * (size_t)(j - 1)];
+	for (int j = n - 1; j >= 0; j--) {
+		const bool nz = b[j] != 0.0;
+		__syncthreads();
+		if (nz) {
+			if (lane == 0) b[j] = b[j] / ab[(size_t)kd + (size_t)ldab * j];
+			__syncthreads();
+			const real_t xj = b[j];
+			const int lo = j - kd > 0 ? j - kd : 0;
+			for (int i = j - 1 - lane; i >= lo; i -= blockDim.x) b[i] = b[i] - xj * ab[(size_t)(kd + i - j) + (size_t)ldab * j];
 		}
+		__syncthreads();
+	}
+}
+
+// stage the factor in LDS when it fits, then solve
+__device__ void band_solve(int n, int kd, const real_t *__restrict__ abd, int ldab, real_t *bbd, real_t *lds, int use_lds)
+{
+	const real_t *ab = abd;
+	real_t *b = bbd;
+	if (use_lds) {
+		real_t *lab = lds, *lb = lds + (size_t)ldab * n;
+		for (int t = threadIdx.x; t < ldab * n; t += blockDim.x) lab[t] = abd[t];
+		for (int t = threadIdx.x; t < n; t += blockDim.x) lb[t] = bbd[t];
+		ab = lab; b = lb;
+	}
+	__syncthreads();
+	dpbtrs_upper_wave(n, kd, ab, ldab, b);
+	if (use_lds) {
+		for (int t = threadIdx.x; t < n; t += blockDim.x) bbd[t] = b[t];
+		__syncthreads();
 	}
 }
 
@@ -88,8 +114,9 @@ __global__ __launch_bounds__(256) void setup_cg2_kernel(const real_t *__restrict
 }
 
 __global__ __launch_bounds__(64) void solve_cg2_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ,
-                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1)
+                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1, int use_lds)
 {
+	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int I1 = II - 1, J1 = JJ - 1, I2 = I1 - 1;
 	const int n = I2 * (J1 - 1);
 	for (int kk = threadIdx.x; kk < n; kk += blockDim.x) {
@@ -97,7 +124,7 @@ __global__ __launch_bounds__(64) void solve_cg2_kernel(real_t *__restrict__ q, c
 		bbd[kk] = qf[(size_t)i + (size_t)II * j];
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) dpbtrs_upper(n, I1, abd, nabd1, bbd);
+	band_solve(n, I1, abd, nabd1, bbd, lds, use_lds);
 	__syncthreads();
 	for (int kk = threadIdx.x; kk < n; kk += blockDim.x) {
 		const int i = kk % I2 + 1, j = kk / I2 + 1;
@@ -112,8 +139,9 @@ void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int na
 
 void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st)
 {
-	(void)nabd2;
-	hipLaunchKernelGGL(solve_cg2_kernel, dim3(1), dim3(64), 0, st, q, qf, II, JJ, abd, bbd, nabd1);
+	size_t shm = ((size_t)nabd1 * nabd2 + nabd2 + 2) * sizeof(real_t);
+	int use_lds = shm <= 60 * 1024;
+	hipLaunchKernelGGL(solve_cg2_kernel, dim3(1), dim3(64), use_lds ? shm : 0, st, q, qf, II, JJ, abd, bbd, nabd1, use_lds);
 }
 
 // ------------------------------------------------------------------ 3D
@@ -149,8 +177,9 @@ __global__ __launch_bounds__(256) void setup_cg3_kernel(const real_t *__restrict
 }
 
 __global__ __launch_bounds__(64) void solve_cg3_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ, int KK,
-                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1)
+                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1, int use_lds)
 {
+	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int i1 = II - 1, j1 = JJ - 1, k1 = KK - 1, i2 = i1 - 1;
 	const int ibw = i2 * j1 + 1;
 	const int nxy = i2 * (j1 - 1), n = nxy * (k1 - 1);
@@ -160,7 +189,7 @@ __global__ __launch_bounds__(64) void solve_cg3_kernel(real_t *__restrict__ q, c
 		bbd[t] = qf[(size_t)i + sj * j + sk * k];
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) dpbtrs_upper(n, ibw, abd, nabd1, bbd);
+	band_solve(n, ibw, abd, nabd1, bbd, lds, use_lds);
 	__syncthreads();
 	for (int t = threadIdx.x; t < n; t += blockDim.x) {
 		const int i = t % i2 + 1, j = (t / i2) % (j1 - 1) + 1, k = t / nxy + 1;
@@ -175,8 +204,9 @@ void setup_cg3(const real_t *so, int II, int JJ, int KK, int nstncl, real_t *abd
 
 void solve_cg3(real_t *q, const real_t *qf, int II, int JJ, int KK, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st)
 {
-	(void)nabd2;
-	hipLaunchKernelGGL(solve_cg3_kernel, dim3(1), dim3(64), 0, st, q, qf, II, JJ, KK, abd, bbd, nabd1);
+	size_t shm = ((size_t)nabd1 * nabd2 + nabd2 + 2) * sizeof(real_t);
+	int use_lds = shm <= 60 * 1024;
+	hipLaunchKernelGGL(solve_cg3_kernel, dim3(1), dim3(64), use_lds ? shm : 0, st, q, qf, II, JJ, KK, abd, bbd, nabd1, use_lds);
 }
 
 } // namespace cedar_amd

@@ -27,31 +27,158 @@ __device__ __forceinline__ real_t gs9_mem(const real_t *__restrict__ so, const r
 	return s;
 }
 
+struct C9 {
+	real_t w, s, sw;        // stored at X:        kw, ks, ksw
+	real_t s_n, nw_n;       // stored at X+(0,1):  ks, knw
+	real_t w_e, nw_e;       // stored at X+(1,0):  kw, knw
+	real_t sw_ne;           // stored at X+(1,1):  ksw
+};
+
+// qq[dj+1][di+1]; term order of BMG2_SymStd_relax_GS.f90:98-107 (= residual.f90:90-98)
+__device__ __forceinline__ real_t offdiag9(real_t qf, const C9 &c, const real_t (&qq)[3][3])
+{
+	real_t s = qf;
+	s = s + c.w * qq[1][0];
+	s = s + c.w_e * qq[1][2];
+	s = s + c.s * qq[0][1];
+	s = s + c.s_n * qq[2][1];
+	s = s + c.sw * qq[0][0];
+	s = s + c.nw_e * qq[0][2];
+	s = s + c.nw_n * qq[2][0];
+	s = s + c.sw_ne * qq[2][2];
+	return s;
+}
+
+__device__ __forceinline__ void ldpair2(const real_t *__restrict__ p, bool two, real_t &a, real_t &b)
+{
+	if (two) {
+		d2u v = *reinterpret_cast<const d2u *>(p);
+		a = v.x; b = v.y;
+	} else {
+		a = p[0]; b = 0.0;
+	}
+}
+
+// all operands of the pair (ie, io) of row `row`: 16-byte loads; `two`: element io+1 inside the row
+__device__ __forceinline__ void load_pair9(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                           const real_t *__restrict__ q, size_t row, size_t sj, size_t PS,
+                                           int ie, int io, bool two, C9 &ce, C9 &co,
+                                           real_t (&qe)[3][3], real_t (&qo)[3][3], real_t &qfe, real_t &qfo)
+{
+	real_t a, b;
+	ldpair2(so + KW * PS + row + ie, true, a, b); ce.w = a; co.w = b; ce.w_e = b;
+	ldpair2(so + KS * PS + row + ie, true, a, b); ce.s = a; co.s = b;
+	ldpair2(so + KSW * PS + row + ie, true, a, b); ce.sw = a; co.sw = b;
+	ldpair2(so + KS * PS + row + sj + ie, true, a, b); ce.s_n = a; co.s_n = b;
+	ldpair2(so + KNW * PS + row + sj + ie, true, a, b); ce.nw_n = a; co.nw_n = b;
+	ldpair2(so + KNW * PS + row + io, two, a, b); ce.nw_e = a; co.nw_e = b;
+	ldpair2(so + KSW * PS + row + sj + io, two, a, b); ce.sw_ne = a; co.sw_ne = b;
+	co.w_e = two ? so[KW * PS + row + io + 1] : 0.0;
+	ldpair2(qf + row + ie, true, qfe, qfo);
+#pragma unroll
+	for (int dj = 0; dj < 3; dj++) {
+		const real_t *r = q + row + (ptrdiff_t)(dj - 1) * (ptrdiff_t)sj;
+		real_t w0, w1, w2, w3;
+		ldpair2(r + ie - 1, true, w0, w1);
+		ldpair2(r + io, two, w2, w3);
+		qe[dj][0] = w0; qe[dj][1] = w1; qe[dj][2] = w2;
+		qo[dj][0] = w1; qo[dj][1] = w2; qo[dj][2] = w3;
+	}
+}
+
 // EFIRST: even 1-based i first (DOWN in 2D), else odd i first (UP).
-// One workgroup per grid row; lanes stride over the row's (i_e, i_o) pairs.
-// Phase 1 relaxes the first i-colour of the whole row in place, phase 2 the
-// second one (it reads the fresh first-colour values back through L1/L2).
-// In-place is safe: within one launch only rows of one parity are written and
-// a row's relaxation reads rows j-1, j+1 (other parity) and itself.
+// One workgroup per grid row; lane p of chunk c owns the pair (i_e,i_o) = (2P+2, 2P+3), P = c*BS+p.
+// Within a chunk the fresh first-colour values reach the neighbouring lane through LDS; between
+// chunks one value is carried: the chunks of a row are walked downwards for EFIRST (the last odd
+// point of a chunk needs the first even point of the next chunk, already relaxed) and upwards
+// otherwise.  In-place is safe: a launch writes rows of one parity only, and inside a row every
+// value that a later chunk still has to read "old" has not been written yet.
 template <int BS, bool EFIRST>
 __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                   real_t *q, const real_t *__restrict__ sor,
+                                                   real_t *__restrict__ q, const real_t *__restrict__ sor,
                                                    int II, int JJ, int jb, int nrows)
 {
+	__shared__ real_t xch[BS + 2];
+	__shared__ real_t carry_s;
 	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nrows);
 	if (L >= (unsigned)nrows) return;
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const size_t row = (size_t)(1 + jb + 2 * (int)L) * sj;
-	const int first = EFIRST ? 1 : 2; // 0-based offset of the first colour's first point
-#pragma unroll 1
-	for (int phase = 0; phase < 2; phase++) {
-		const int start = phase == 0 ? first : 3 - first;
-		for (int i = start + 2 * (int)threadIdx.x; i <= II - 2; i += 2 * BS) {
-			const size_t x = row + i;
-			q[x] = gs9_mem(so, qf, q, sj, PS, x) * sor[PS + x];
+	const int npairs = (II - 2 + 1) / 2;
+	const int nchunks = (npairs + BS - 1) / BS;
+	const int t = threadIdx.x;
+	for (int cc = 0; cc < nchunks; cc++) {
+		const int c = EFIRST ? nchunks - 1 - cc : cc;
+		const int p = c * BS + t;
+		const int ie = 2 * p + 1, io = ie + 1;
+		const bool e_ok = ie <= II - 2, o_ok = io <= II - 2, two = io + 1 <= II - 1;
+		C9 ce, co;
+		real_t qe[3][3], qo[3][3], qfe = 0, qfo = 0, sre = 0, sro = 0, e_new = 0, o_new = 0;
+		if (e_ok) {
+			load_pair9(so, qf, q, row, sj, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+			ldpair2(sor + PS + row + ie, true, sre, sro);
 		}
-		__syncthreads(); // workgroup-scope release/acquire: phase 2 sees phase 1's stores
+		const real_t carry = carry_s; // written by the previous chunk iteration (unused in the first)
+		if (EFIRST) {
+			if (e_ok) { e_new = offdiag9(qfe, ce, qe) * sre; xch[t] = e_new; }
+			__syncthreads();
+			if (o_ok) {
+				qo[1][0] = e_new;
+				if (io + 1 <= II - 2) qo[1][2] = (t < BS - 1) ? xch[t + 1] : carry; // next pair's fresh even point
+				o_new = offdiag9(qfo, co, qo) * sro;
+			}
+			if (t == 0) carry_s = e_new; // first even point of this chunk, for the chunk below
+		} else {
+			if (o_ok) { o_new = offdiag9(qfo, co, qo) * sro; xch[t + 1] = o_new; }
+			__syncthreads();
+			if (e_ok) {
+				if (p > 0) qe[1][0] = (t > 0) ? xch[t] : carry; // previous pair's fresh odd point
+				if (o_ok) qe[1][2] = o_new;
+				e_new = offdiag9(qfe, ce, qe) * sre;
+			}
+			if (t == BS - 1) carry_s = o_new;
+		}
+		if (e_ok) {
+			if (o_ok) {
+				d2u v; v.x = e_new; v.y = o_new;
+				*reinterpret_cast<d2u *>(q + row + ie) = v;
+			} else
+				q[row + ie] = e_new;
+		}
+		__syncthreads(); // stores + carry visible before the next chunk loads / reads them
 	}
+}
+
+// 9-point residual, pair per lane, 16-byte loads (BMG2_SymStd_residual.f90:88-99)
+__global__ __launch_bounds__(256) void residual9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                       const real_t *__restrict__ q, real_t *__restrict__ res,
+                                                       int II, int JJ, unsigned nrows)
+{
+	const unsigned L = xcd_remap(blockIdx.x, nrows);
+	if (L >= nrows) return;
+	const size_t sj = II, PS = (size_t)II * JJ;
+	const size_t row = (size_t)(L + 1) * sj;
+	for (int p = threadIdx.x; 2 * p + 1 <= II - 2; p += blockDim.x) {
+		const int ie = 2 * p + 1, io = ie + 1;
+		const bool o_ok = io <= II - 2, two = io + 1 <= II - 1;
+		C9 ce, co;
+		real_t qe[3][3], qo[3][3], qfe, qfo, de, dn;
+		load_pair9(so, qf, q, row, sj, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		ldpair2(so + row + ie, true, de, dn); // KO plane
+		const real_t re = offdiag9(qfe, ce, qe) - de * qe[1][1];
+		if (o_ok) {
+			const real_t ro = offdiag9(qfo, co, qo) - dn * qo[1][1];
+			d2u v; v.x = re; v.y = ro;
+			*reinterpret_cast<d2u *>(res + row + ie) = v;
+		} else
+			res[row + ie] = re;
+	}
+}
+
+void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st)
+{
+	unsigned nrows = (unsigned)(JJ - 2);
+	hipLaunchKernelGGL(residual9_rows, dim3(xcd_grid(nrows)), dim3((II - 2) / 2 >= 256 ? 256 : 64), 0, st, so, qf, q, res, II, JJ, nrows);
 }
 
 // 5-point red-black, one colour per launch (relax_GS.f90:120-135): colour = mod(j+jo,2)

@@ -150,6 +150,56 @@ __device__ __forceinline__ void ldpair(const real_t *__restrict__ p, bool two, r
 	}
 }
 
+// all operands of the pair (ie, io) of one row: 26 coefficients per point, qf, and the 3x3 q rows
+// (offsets ie-1 .. io+1); 16-byte loads, `two` = element io+1 is still inside the row
+__device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                            const real_t *__restrict__ q, size_t row, size_t sj, size_t sk, size_t PS,
+                                            int ie, int io, bool two, C27 &ce, C27 &co,
+                                            real_t (&qe)[3][3][3], real_t (&qo)[3][3][3], real_t &qfe, real_t &qfo)
+{
+	// ---- [i]-pattern streams: (value at ie, value at io)
+#define LD_I(slot, off, fe, fo)                                                        \
+{                                                                                  \
+	real_t a_, b_;                                                                 \
+	ldpair(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);               \
+	ce.fe = a_; co.fo = b_;                                                        \
+}
+	LD_I(KPW, 0, pw, pw) LD_I(KPS, 0, ps, ps) LD_I(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
+	LD_I(KBW, 0, bw, bw) LD_I(KBS, 0, bs, bs) LD_I(KBSW, 0, bsw, bsw)
+	LD_I(KPNW, sj, pnw_n, pnw_n) LD_I(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
+	LD_I(KB, sk, b_t, b_t) LD_I(KBE, sk, be_t, be_t) LD_I(KBN, sk, bn_t, bn_t) LD_I(KBNE, sk, bne_t, bne_t)
+	LD_I(KBSE, sj + sk, bse_nt, bse_nt) LD_I(KBS, sj + sk, bs_nt, bs_nt)
+#undef LD_I
+	// ---- [i+1]-pattern streams: (value at ie+1 = io, value at io+1)
+#define LD_IP(slot, off, f)                                                            \
+{                                                                                  \
+	real_t a_, b_;                                                                 \
+	ldpair(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);                \
+	ce.f = a_; co.f = b_;                                                          \
+}
+	LD_IP(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
+	LD_IP(KPW, 0, pw_e) LD_IP(KPNW, 0, pnw_e) LD_IP(KBE, 0, be_e) LD_IP(KBSE, 0, bse_e)
+	LD_IP(KBSW, sj + sk, bsw_net)
+	LD_IP(KBW, sk, bw_et) LD_IP(KBNW, sk, bnw_et)
+#undef LD_IP
+	{
+		real_t a_, b_;
+		ldpair(qf + row + ie, true, a_, b_); qfe = a_; qfo = b_;
+	}
+	// ---- q windows: offsets ie-1 .. io+1 of the nine rows
+#pragma unroll
+	for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+		for (int dj = 0; dj < 3; dj++) {
+			const real_t *r = q + row + (ptrdiff_t)(dj - 1) * (ptrdiff_t)sj + (ptrdiff_t)(dk - 1) * (ptrdiff_t)sk;
+			real_t w0, w1, w2, w3;
+			ldpair(r + ie - 1, true, w0, w1);
+			ldpair(r + io, two, w2, w3);
+			qe[dk][dj][0] = w0; qe[dk][dj][1] = w1; qe[dk][dj][2] = w2;
+			qo[dk][dj][0] = w1; qo[dk][dj][1] = w2; qo[dk][dj][2] = w3;
+		}
+}
+
 // fast path: one workgroup = one grid row, both i-colours.
 //   EFIRST = true : colour with even 1-based i (i = 2,4,..) first  (UP order)
 //   EFIRST = false: odd i first                                     (DOWN order)
@@ -179,48 +229,9 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 	real_t qfe = 0, qfo = 0, sre = 0, sro = 0;
 
 	if (e_ok) {
-		// ---- [i]-pattern streams: (value at ie, value at io)
-#define LD_I(slot, off, fe, fo)                                                        \
-	{                                                                                  \
-		real_t a_, b_;                                                                 \
-		ldpair(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);               \
-		ce.fe = a_; co.fo = b_;                                                        \
-	}
-		LD_I(KPW, 0, pw, pw) LD_I(KPS, 0, ps, ps) LD_I(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
-		LD_I(KBW, 0, bw, bw) LD_I(KBS, 0, bs, bs) LD_I(KBSW, 0, bsw, bsw)
-		LD_I(KPNW, sj, pnw_n, pnw_n) LD_I(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
-		LD_I(KB, sk, b_t, b_t) LD_I(KBE, sk, be_t, be_t) LD_I(KBN, sk, bn_t, bn_t) LD_I(KBNE, sk, bne_t, bne_t)
-		LD_I(KBSE, sj + sk, bse_nt, bse_nt) LD_I(KBS, sj + sk, bs_nt, bs_nt)
-#undef LD_I
-		// ---- [i+1]-pattern streams: (value at ie+1 = io, value at io+1)
-#define LD_IP(slot, off, f)                                                            \
-	{                                                                                  \
-		real_t a_, b_;                                                                 \
-		ldpair(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);                \
-		ce.f = a_; co.f = b_;                                                          \
-	}
-		LD_IP(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
-		LD_IP(KPW, 0, pw_e) LD_IP(KPNW, 0, pnw_e) LD_IP(KBE, 0, be_e) LD_IP(KBSE, 0, bse_e)
-		LD_IP(KBSW, sj + sk, bsw_net)
-		LD_IP(KBW, sk, bw_et) LD_IP(KBNW, sk, bnw_et)
-#undef LD_IP
-		{
-			real_t a_, b_;
-			ldpair(qf + row + ie, true, a_, b_); qfe = a_; qfo = b_;
-			ldpair(sor + PS + row + ie, true, a_, b_); sre = a_; sro = b_;
-		}
-		// ---- q windows: offsets ie-1 .. io+1 of the nine rows
-#pragma unroll
-		for (int dk = 0; dk < 3; dk++)
-#pragma unroll
-			for (int dj = 0; dj < 3; dj++) {
-				const real_t *r = q + row + (ptrdiff_t)(dj - 1) * (ptrdiff_t)sj + (ptrdiff_t)(dk - 1) * (ptrdiff_t)sk;
-				real_t w0, w1, w2, w3;
-				ldpair(r + ie - 1, true, w0, w1);
-				ldpair(r + io, two, w2, w3);
-				qe[dk][dj][0] = w0; qe[dk][dj][1] = w1; qe[dk][dj][2] = w2;
-				qo[dk][dj][0] = w1; qo[dk][dj][1] = w2; qo[dk][dj][2] = w3;
-			}
+		load_pair27(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		real_t a_, b_;
+		ldpair(sor + PS + row + ie, true, a_, b_); sre = a_; sro = b_;
 	}
 
 	if (EFIRST) {
@@ -281,6 +292,45 @@ __global__ void relax7_colour(const real_t *__restrict__ so, const real_t *__res
 		s = s + so[KB * PS + x + sk] * q[x + sk];
 		q[x] = s * sor[PS + x];
 	}
+}
+
+// 27-point residual with the same lane layout as the relax row kernel: lane p owns the pair
+// (2p+1, 2p+2) of its row, every stream is read with 16-byte loads, one 16-byte store.
+// (BMG3_SymStd_residual.f90:77-104; bit-identical term order.)
+template <int BS>
+__global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                       const real_t *__restrict__ q, real_t *__restrict__ res,
+                                                       int II, int JJ, int KK, unsigned nrows)
+{
+	const unsigned L = xcd_remap(blockIdx.x, nrows);
+	if (L >= nrows) return;
+	const size_t j = (size_t)(L % (unsigned)(JJ - 2)) + 1, k = (size_t)(L / (unsigned)(JJ - 2)) + 1;
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
+	const size_t row = j * sj + k * sk;
+	for (int p = threadIdx.x; 2 * p + 1 <= II - 2; p += BS) {
+		const int ie = 2 * p + 1, io = 2 * p + 2;
+		const bool o_ok = io <= II - 2, two = io + 1 <= II - 1;
+		C27 ce, co;
+		real_t qe[3][3][3], qo[3][3][3], qfe, qfo, de, dn;
+		load_pair27(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		ldpair(so + row + ie, true, de, dn); // KP plane
+		const real_t re = offdiag27(qfe, ce, qe) - de * qe[1][1][1];
+		if (o_ok) {
+			const real_t ro = offdiag27(qfo, co, qo) - dn * qo[1][1][1];
+			d2u v; v.x = re; v.y = ro;
+			*reinterpret_cast<d2u *>(res + row + ie) = v;
+		} else
+			res[row + ie] = re;
+	}
+}
+
+void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st)
+{
+	unsigned nrows = (unsigned)(JJ - 2) * (unsigned)(KK - 2);
+	const int npairs = (II - 2 + 1) / 2;
+	if (npairs <= 64) hipLaunchKernelGGL(residual27_rows<64>, dim3(xcd_grid(nrows)), dim3(64), 0, st, so, qf, q, res, II, JJ, KK, nrows);
+	else if (npairs <= 128) hipLaunchKernelGGL(residual27_rows<128>, dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows);
+	else hipLaunchKernelGGL(residual27_rows<256>, dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows);
 }
 
 static inline unsigned cap_grid(size_t n, unsigned bs)

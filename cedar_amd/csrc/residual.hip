@@ -37,10 +37,16 @@ __global__ __launch_bounds__(256) void residual2_kernel(const real_t *__restrict
 	res[x] = s;
 }
 
+void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st);
+
 void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int nstncl, hipStream_t st)
 {
 	if (II < 3 || JJ < 3) return;
+	if (nstncl == 5) { // pair-per-lane row kernel (relax2d.hip)
+		residual9_fast(so, qf, q, res, II, JJ, st);
+		return;
+	}
 	dim3 grid((II - 2 + 255) / 256, JJ - 2);
 	if (nstncl == 5)
 		hipLaunchKernelGGL(residual2_kernel<true>, grid, dim3(256), 0, st, so, qf, q, res, II, JJ);
@@ -101,10 +107,16 @@ __global__ __launch_bounds__(256) void residual3_kernel(const real_t *__restrict
 	}
 }
 
+void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st);
+
 void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int KK, int nstncl, hipStream_t st)
 {
 	if (II < 3 || JJ < 3 || KK < 3) return;
+	if (nstncl == 14) { // pair-per-lane row kernel (relax3d.hip)
+		residual27_fast(so, qf, q, res, II, JJ, KK, st);
+		return;
+	}
 	unsigned nrows = (unsigned)(JJ - 2) * (unsigned)(KK - 2);
 	int bs = II - 2 >= 256 ? 256 : (II - 2 > 64 ? 128 : 64);
 	if (nstncl == 14)
