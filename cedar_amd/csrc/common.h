@@ -113,4 +113,26 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
 }
 static inline unsigned xcd_grid(unsigned nblk) { return ((nblk + 7u) >> 3) << 3; }
 
+// Row (jr,kr) owned by logical workgroup L: rows are walked in 2^tjl x 2^tkl (j,k) tiles so that
+// the ~64 workgroups an XCD has in flight form a compact patch of rows and find each other's rows
+// (q rows j+-1,k+-1; operator rows stored at j+1 / k+1) in that XCD's L2 instead of HBM.
+// tkl = 0 degenerates to the plain j-fastest walk.
+struct TileShape { unsigned tjl, tkl; };
+__device__ __forceinline__ bool tile_rows(unsigned L, unsigned nj, unsigned nk, TileShape ts, unsigned &jr, unsigned &kr)
+{
+	const unsigned ntj = (nj + (1u << ts.tjl) - 1u) >> ts.tjl;
+	const unsigned tile = L >> (ts.tjl + ts.tkl), w = L & ((1u << (ts.tjl + ts.tkl)) - 1u);
+	jr = ((tile % ntj) << ts.tjl) + (w & ((1u << ts.tjl) - 1u));
+	kr = ((tile / ntj) << ts.tkl) + (w >> ts.tjl);
+	return jr < nj && kr < nk;
+}
+__host__ __device__ static inline unsigned tile_blocks(unsigned nj, unsigned nk, TileShape ts)
+{
+	return (((nj + (1u << ts.tjl) - 1u) >> ts.tjl) * ((nk + (1u << ts.tkl) - 1u) >> ts.tkl)) << (ts.tjl + ts.tkl);
+}
+// default shapes (measured on MI355X, profiles/): overridable for experiments with
+// CEDAR_AMD_TILE_RELAX="tjl,tkl" / CEDAR_AMD_TILE_RESID="tjl,tkl"
+TileShape tile_shape_relax();
+TileShape tile_shape_resid();
+
 } // namespace cedar_amd

@@ -22,6 +22,18 @@
 
 namespace cedar_amd {
 
+static TileShape env_tile(const char *name, unsigned tjl, unsigned tkl)
+{
+	TileShape ts{tjl, tkl};
+	if (const char *e = getenv(name)) {
+		unsigned a, b;
+		if (sscanf(e, "%u,%u", &a, &b) == 2 && a <= 8 && b <= 8) { ts.tjl = a; ts.tkl = b; }
+	}
+	return ts;
+}
+TileShape tile_shape_relax() { static TileShape ts = env_tile("CEDAR_AMD_TILE_RELAX", 4, 4); return ts; }
+TileShape tile_shape_resid() { static TileShape ts = env_tile("CEDAR_AMD_TILE_RESID", 4, 4); return ts; }
+
 // ------------------------------------------------------------------ recip
 __global__ void recip_kernel(const real_t *__restrict__ d, real_t *__restrict__ r,
                              int II, int JJ, int KK)
@@ -206,14 +218,15 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 template <int BS, bool EFIRST>
 __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                     real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                    int II, int JJ, int KK, int jb, int kb, int nrj, int nrk)
+                                                    int II, int JJ, int KK, int jb, int kb, int nrj, int nrk, TileShape ts,
+                                                    int kr0)
 {
 	__shared__ real_t xch[BS + 2];
-	const unsigned nblk = (unsigned)nrj * (unsigned)nrk;
+	const unsigned nblk = tile_blocks((unsigned)nrj, (unsigned)nrk, ts);
 	const unsigned L = xcd_remap(blockIdx.x, nblk);
-	if (L >= nblk) return; // whole workgroup leaves together
-	const int jr = (int)(L % (unsigned)nrj), kr = (int)(L / (unsigned)nrj);
-	const size_t j = (size_t)(1 + jb + 2 * jr), k = (size_t)(1 + kb + 2 * kr); // 0-based incl. ghost
+	unsigned jr, kr;
+	if (L >= nblk || !tile_rows(L, (unsigned)nrj, (unsigned)nrk, ts, jr, kr)) return; // whole workgroup leaves together
+	const size_t j = (size_t)(1 + jb + 2 * (int)jr), k = (size_t)(1 + kb + 2 * ((int)kr + kr0)); // 0-based incl. ghost
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
 	const size_t row = j * sj + k * sk;
 
@@ -300,11 +313,12 @@ __global__ void relax7_colour(const real_t *__restrict__ so, const real_t *__res
 template <int BS>
 __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                        const real_t *__restrict__ q, real_t *__restrict__ res,
-                                                       int II, int JJ, int KK, unsigned nrows)
+                                                       int II, int JJ, int KK, unsigned nblk, TileShape ts)
 {
-	const unsigned L = xcd_remap(blockIdx.x, nrows);
-	if (L >= nrows) return;
-	const size_t j = (size_t)(L % (unsigned)(JJ - 2)) + 1, k = (size_t)(L / (unsigned)(JJ - 2)) + 1;
+	const unsigned L = xcd_remap(blockIdx.x, nblk);
+	unsigned jr, kr;
+	if (L >= nblk || !tile_rows(L, (unsigned)(JJ - 2), (unsigned)(KK - 2), ts, jr, kr)) return;
+	const size_t j = (size_t)jr + 1, k = (size_t)kr + 1;
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
 	const size_t row = j * sj + k * sk;
 	for (int p = threadIdx.x; 2 * p + 1 <= II - 2; p += BS) {
@@ -326,11 +340,12 @@ __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__
 
 void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st)
 {
-	unsigned nrows = (unsigned)(JJ - 2) * (unsigned)(KK - 2);
+	const TileShape ts = tile_shape_resid();
+	unsigned nrows = tile_blocks((unsigned)(JJ - 2), (unsigned)(KK - 2), ts);
 	const int npairs = (II - 2 + 1) / 2;
-	if (npairs <= 64) hipLaunchKernelGGL(residual27_rows<64>, dim3(xcd_grid(nrows)), dim3(64), 0, st, so, qf, q, res, II, JJ, KK, nrows);
-	else if (npairs <= 128) hipLaunchKernelGGL(residual27_rows<128>, dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows);
-	else hipLaunchKernelGGL(residual27_rows<256>, dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows);
+	if (npairs <= 64) hipLaunchKernelGGL(residual27_rows<64>, dim3(xcd_grid(nrows)), dim3(64), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+	else if (npairs <= 128) hipLaunchKernelGGL(residual27_rows<128>, dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+	else hipLaunchKernelGGL(residual27_rows<256>, dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 }
 
 static inline unsigned cap_grid(size_t n, unsigned bs)
@@ -341,17 +356,20 @@ static inline unsigned cap_grid(size_t n, unsigned bs)
 	return (unsigned)g;
 }
 
+// rows kr0 .. kr0+nrk_slab-1 (in units of rows of this k-parity) of the row class; nrk_slab < 0: all
 template <int BS>
 static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                        int II, int JJ, int KK, int jb, int kb, hipStream_t st)
+                        int II, int JJ, int KK, int jb, int kb, hipStream_t st, int kr0 = 0, int nrk_slab = -1)
 {
 	int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	if (nrk_slab >= 0) { nrk = nrk - kr0 < nrk_slab ? nrk - kr0 : nrk_slab; }
 	if (nrj <= 0 || nrk <= 0) return;
-	unsigned grid = xcd_grid((unsigned)nrj * (unsigned)nrk);
+	const TileShape ts = tile_shape_relax();
+	unsigned grid = xcd_grid(tile_blocks((unsigned)nrj, (unsigned)nrk, ts));
 	if (efirst)
-		hipLaunchKernelGGL((relax27_rows<BS, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk);
+		hipLaunchKernelGGL((relax27_rows<BS, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
 	else
-		hipLaunchKernelGGL((relax27_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk);
+		hipLaunchKernelGGL((relax27_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
 }
 
 // one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs
