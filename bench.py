@@ -165,7 +165,7 @@ def main():
                 dsolver.vcycle(xt, bt)
 
             def nlevels(self):
-                return len(dsolver.levels)
+                return dsolver.nlev_global
 
             def time_relax(self, x_, b_, k):
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -256,6 +256,8 @@ def _vp(a):
         return None
     if isinstance(a, DeviceArray):
         return a.ptr
+    if hasattr(a, "data_ptr"):  # torch tensor (device or host), contiguous float64
+        return a.data_ptr()
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data
 

@@ -32,8 +32,11 @@ Two places need more than "exchange after the kernel":
     code; on a side with a neighbouring rank the lower bound becomes 2
     (`cedar_amd_setup_interp3_phase(..., ilo, jlo, klo)`) and CI ghosts are
     exchanged between the dependent phases.
-The coarsest grid (global 4..8 points per direction) is assembled on every rank
-by all-gather and solved redundantly with the serial band Cholesky.
+Coarse levels are latency-bound (a 32^3 block per GPU is microseconds of work between
+exchanges), so below `agglomerate_below` points per direction the level is assembled on every
+rank by all-gather and the rest of the cycle runs redundantly on the single-domain solver
+(one hipGraph replay on the GPU).  This replaces the reference's redistribution solver
+(include/cedar/3d/mpi/redist_solver.h) and, at the last level, its coarsest-grid gather.
 
 The orchestration is backend-agnostic: `GpuBackend` (below) drives the HIP
 kernels through the C ABI on torch CUDA tensors; the test-suite supplies a CPU
@@ -267,13 +270,18 @@ class GpuBackend:
         f = self.lib.BMG3_SymStd_SETUP_ITLI07_ex if A.shape[0] == 4 else self.lib.BMG3_SymStd_SETUP_ITLI27_ex
         f(self._p(A), self._p(Ac), self._p(P), *self._dims(A), *self._dims(Ac), 0)
 
-    def setup_cg(self, A, abd):
-        n2, n1 = abd.shape
-        self.lib.BMG3_SymStd_SETUP_cg_LU(self._p(A), *self._dims(A), A.shape[0], self._p(abd), C.c_uint(n1), C.c_uint(n2), 0)
+    def make_serial(self, gA, pre, post, min_coarse, num_levels):
+        """single-domain device-resident solver on the gathered level (V-cycle = one graph replay)"""
+        capi = self.capi
 
-    def solve_cg(self, x, b, abd, bbd):
-        n2, n1 = abd.shape
-        self.lib.BMG3_SymStd_SOLVE_cg(self._p(x), self._p(b), *self._dims(x), self._p(abd), self._p(bbd), C.c_uint(n1), C.c_uint(n2), 0)
+        class _H:
+            def __init__(h):
+                h.s = capi.Solver(gA, nrelax_pre=pre, nrelax_post=post, min_coarse=min_coarse,
+                                  num_levels=num_levels, share_operator=True)
+
+            def vcycle(h, x, b):
+                capi.lib.cedar_amd_solver_vcycle(h.s.h, x.data_ptr(), b.data_ptr())
+        return _H()
 
     def sumsq(self, r):
         v = self.capi.lib.cedar_amd_l2norm(r.data_ptr(), r.shape[2], r.shape[1], r.shape[0])
@@ -291,11 +299,13 @@ class Level:
 class DistSolver3:
     """cedar::cdr3::mpi::solver equivalent for Dirichlet problems, point relaxation, V(pre,post)."""
 
-    def __init__(self, backend, topo, A_local, nrelax_pre=2, nrelax_post=1, min_coarse=3, max_iter=10, tol=1e-8):
+    def __init__(self, backend, topo, A_local, nrelax_pre=2, nrelax_post=1, min_coarse=3, max_iter=10, tol=1e-8,
+                 agglomerate_below=32):
         """A_local: (nst, nz+2, ny+2, nx+2) local part of the global operator (ghost layers are
         filled here by exchange; entries coupling to a neighbouring rank must be present)."""
         self.be, self.topo = backend, topo
         self.pre, self.post, self.max_iter, self.tol = nrelax_pre, nrelax_post, max_iter, tol
+        self.min_coarse = min_coarse
         staged = dist.is_initialized() and dist.get_backend() == "gloo" and A_local.is_cuda
         nst = A_local.shape[0]
         n = tuple(int(s) - 2 for s in A_local.shape[1:][::-1])
@@ -307,12 +317,21 @@ class DistSolver3:
             ng += 1
             if min((g - 1) // (1 << ng) + 1 for g in gn) < min_coarse:
                 break
+        self.nlev_global = ng
+        # distributed levels 0..la; level la is gathered and handed to the single-domain solver
+        la, m = ng - 1, n
+        for l in range(1, ng):
+            m = tuple(int((v - 1) / 2.0 + 1) if p[d] == 1 else v // 2 for d, v in enumerate(m))
+            if min(m[d] for d in range(3) if p[d] > 1 or True) <= agglomerate_below:
+                la = l
+                break
+        self.la = max(la, 1) if ng > 1 else 0
         self.levels = []
-        for l in range(ng):
+        for l in range(self.la + 1):
             L = Level()
             L.n = n
             for d in range(3):
-                if p[d] > 1 and l < ng - 1:
+                if p[d] > 1 and l < self.la:
                     assert n[d] % 2 == 0, f"level {l}: local extent {n[d]} in dim {d} must be even"
             shp = (n[2] + 2, n[1] + 2, n[0] + 2)
             L.halo = Halo(topo, n, A_local.device, staged)
@@ -343,18 +362,15 @@ class DistSolver3:
             be.galerkin(F.A, K.A, K.P)
             K.halo.exchange(K.A)
             be.recip(F.A, F.sor)
-        # coarsest: assemble the global operator on every rank, factor redundantly
+        # level la: assemble the global operator on every rank; the single-domain solver takes over
         Cl = self.levels[-1]
         self.cn = Cl.n
         p = t.p
         gshape = (Cl.n[2] * p[2] + 2, Cl.n[1] * p[1] + 2, Cl.n[0] * p[0] + 2)
-        self.gA = be.zeros((14,) + gshape)
+        self.gA = be.zeros((Cl.A.shape[0],) + gshape)
         self._gather_into(Cl.A, self.gA)
-        gnx, gny, gnz = gshape[2] - 2, gshape[1] - 2, gshape[0] - 2
-        self.abd = be.zeros((gnx * gny * gnz, gnx * (gny + 1) + 2))
-        self.bbd = be.zeros((gnx * gny * gnz,))
         self.gx, self.gb = be.zeros(gshape), be.zeros(gshape)
-        be.setup_cg(self.gA, self.abd)
+        self.serial = be.make_serial(self.gA, self.pre, self.post, self.min_coarse, self.nlev_global - self.la)
 
     def _gather_into(self, local, glob):
         """all-gather the owned block of `local` (..., KK,JJ,II) into the global array"""
@@ -397,9 +413,12 @@ class DistSolver3:
                 L.halo.exchange(x)
 
     def _coarse_solve(self, x, b):
-        be, t = self.be, self.topo
+        """levels la.. : gather the right-hand side, one single-domain cycle (or the direct solve when
+        la is the coarsest level) from a zero initial guess, keep the own block + ghosts"""
+        t = self.topo
         self._gather_into(b, self.gb)
-        be.solve_cg(self.gx, self.gb, self.abd, self.bbd)
+        self.gx.zero_()
+        self.serial.vcycle(self.gx, self.gb)
         nx, ny, nz = self.cn
         ci, cj, ck = t.coord
         # own block plus ghost layer straight from the global solution

@@ -50,11 +50,16 @@ class CpuBackend:
     def galerkin(self, A, Ac, P):
         self.O.galerkin3(self._n(A), self._n(Ac), self._n(P))
 
-    def setup_cg(self, A, abd):
-        self.O.setup_cg3(self._n(A), self._n(abd))
+    def make_serial(self, gA, pre, post, min_coarse, num_levels):
+        O = self.O
 
-    def solve_cg(self, x, b, abd, bbd):
-        self.O.solve_cg3(self._n(x), self._n(b), self._n(abd))
+        class _H:
+            def __init__(h):
+                h.ml = O.ml_create(gA.numpy(), nrelax_pre=pre, nrelax_post=post, min_coarse=min_coarse, num_levels=num_levels)
+
+            def vcycle(h, x, b):
+                h.ml.vcycle(x.numpy(), b.numpy())
+        return _H()
 
     def sumsq(self, r):
         v = self.O.l2(self._n(r))

@@ -37,7 +37,7 @@ def _worker(rank, world, port, case, outdir):
         import problems as pb
         from cedar_amd.dist import DistSolver3, Topology
         from dist_cpu_backend import CpuBackend
-        kind, n, pgrid = case
+        kind, n, pgrid, agg = case
         topo = Topology(rank, world, pgrid)
         gn = tuple(n[d] * topo.p[d] for d in range(3))
         gso, gb = build_global(pb, kind, gn)
@@ -50,12 +50,12 @@ def _worker(rank, world, port, case, outdir):
         A *= m
         b = torch.from_numpy(np.ascontiguousarray(gb[sl])) * m
         x = torch.zeros_like(b)
-        s = DistSolver3(CpuBackend(), topo, A, max_iter=6)
+        s = DistSolver3(CpuBackend(), topo, A, max_iter=6, agglomerate_below=agg)
         h = s.solve(b, x)
         np.save(os.path.join(outdir, f"x{rank}.npy"), x.numpy())
         if rank == 0:
             np.save(os.path.join(outdir, "hist.npy"), np.array(h))
-            np.save(os.path.join(outdir, "nlev.npy"), np.array([len(s.levels)]))
+            np.save(os.path.join(outdir, "nlev.npy"), np.array([s.nlev_global, s.la]))
     finally:
         dist.destroy_process_group()
 
@@ -71,19 +71,23 @@ def build_global(pb, kind, gn):
     raise ValueError(kind)
 
 
+# (operator, local extents, rank grid, agglomerate_below): 2 = every level distributed down to the
+# coarsest direct solve; 32 = gather after the first coarsening (single-domain solver takes over)
 CASES = [
-    ("fe27", (8, 8, 8), (2, 1, 1)),
-    ("rand27", (8, 6, 5), (2, 1, 1)),
-    ("rand27", (8, 8, 4), (2, 2, 1)),
-    ("poisson7", (8, 8, 8), (2, 1, 1)),
-    ("rand27", (4, 4, 4), (2, 2, 2)),
+    ("fe27", (8, 8, 8), (2, 1, 1), 2),
+    ("rand27", (8, 6, 5), (2, 1, 1), 2),
+    ("rand27", (16, 8, 8), (2, 1, 1), 4),
+    ("rand27", (8, 8, 4), (2, 2, 1), 2),
+    ("poisson7", (8, 8, 8), (2, 1, 1), 2),
+    ("rand27", (4, 4, 4), (2, 2, 2), 2),
+    ("rand27", (8, 8, 8), (2, 2, 2), 32),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-p{'x'.join(map(str, c[2]))}")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-p{'x'.join(map(str, c[2]))}-agg{c[3]}")
 def test_distributed_equals_single_domain(case, tmp_path, oracle):
     import problems as pb
-    kind, n, pgrid = case
+    kind, n, pgrid, agg = case
     world = pgrid[0] * pgrid[1] * pgrid[2]
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     gn = tuple(n[d] * pgrid[d] for d in range(3))
