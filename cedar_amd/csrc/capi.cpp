@@ -356,6 +356,12 @@ void cedar_amd_setup_interp3_phase(real_t *so, real_t *ci, len_t iif, len_t jjf,
 	                    phase, ilo, jlo, klo, current_stream());
 }
 
+void cedar_amd_box_copy(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, int nboxes,
+                        const int *boxes, const unsigned long long *offsets, real_t *buf, int unpack)
+{
+	box_copy(arr, (int)ii, (int)jj, (int)kk, nplanes, nboxes, boxes, offsets, buf, unpack, current_stream());
+}
+
 // ------------------------------------------------------------------ 3D drop-ins
 void BMG3_SymStd_SETUP_recip(real_t *so, real_t *sor, len_t nx, len_t ny, len_t nz, int nstencl, int nsorv)
 {

@@ -232,4 +232,50 @@ void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, con
 	                   IIC, JJC, KKC, IIF, JJF, KKF, imax_e, imax_all, jmax, kmax_e, kmax_o, nrows);
 }
 
+// ------------------------------------------------------------------ halo pack / unpack
+// Copies up to 26 sub-boxes of a (planes x KK x JJ x II) array to / from one contiguous buffer in a
+// single launch (blockIdx.y = box): the pack and unpack steps of the ghost-layer exchange that
+// replaces the MSG gather/scatter index lists of the reference (src/2d/ftn/mpi/mpi_msg.F:483-550).
+struct BoxTable {
+	int n;
+	int i0[26], j0[26], k0[26], ni[26], nj[26], nk[26];
+	unsigned long long off[26]; // offset of the box (first plane) in the buffer, in doubles
+};
+
+__global__ __launch_bounds__(256) void box_copy_kernel(real_t *__restrict__ arr, int II, int JJ, int KK, int nplanes,
+                                                        BoxTable tab, real_t *__restrict__ buf, int unpack)
+{
+	const int bx = blockIdx.y;
+	const int ni = tab.ni[bx], nj = tab.nj[bx], nk = tab.nk[bx];
+	const size_t nbox = (size_t)ni * nj * nk, ntot = nbox * (size_t)nplanes;
+	const size_t PS = (size_t)II * JJ * KK;
+	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < ntot; t += (size_t)gridDim.x * blockDim.x) {
+		const size_t pl = t / nbox, r = t % nbox;
+		const int i = (int)(r % ni), j = (int)((r / ni) % nj), k = (int)(r / ((size_t)ni * nj));
+		const size_t a = pl * PS + (size_t)(tab.i0[bx] + i) + (size_t)II * ((size_t)(tab.j0[bx] + j) + (size_t)JJ * (size_t)(tab.k0[bx] + k));
+		const size_t b = tab.off[bx] * (size_t)nplanes + t;
+		if (unpack) arr[a] = buf[b];
+		else buf[b] = arr[a];
+	}
+}
+
+void box_copy(real_t *arr, int II, int JJ, int KK, int nplanes, int nboxes, const int *boxes /* 6 per box */,
+              const unsigned long long *offsets, real_t *buf, int unpack, hipStream_t st)
+{
+	if (nboxes <= 0) return;
+	BoxTable tab;
+	tab.n = nboxes;
+	size_t maxn = 1;
+	for (int b = 0; b < nboxes && b < 26; b++) {
+		tab.i0[b] = boxes[6 * b]; tab.j0[b] = boxes[6 * b + 1]; tab.k0[b] = boxes[6 * b + 2];
+		tab.ni[b] = boxes[6 * b + 3]; tab.nj[b] = boxes[6 * b + 4]; tab.nk[b] = boxes[6 * b + 5];
+		tab.off[b] = offsets[b];
+		size_t n = (size_t)tab.ni[b] * tab.nj[b] * tab.nk[b] * nplanes;
+		if (n > maxn) maxn = n;
+	}
+	unsigned gx = (unsigned)((maxn + 255) / 256);
+	if (gx > 2048) gx = 2048;
+	hipLaunchKernelGGL(box_copy_kernel, dim3(gx, nboxes), dim3(256), 0, st, arr, II, JJ, KK, nplanes, tab, buf, unpack);
+}
+
 } // namespace cedar_amd

@@ -53,8 +53,9 @@ DOWN, UP = 0, 1
 
 # ------------------------------------------------------------------ topology
 def rank_grid(world):
-    """1 -> 1x1x1, 2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2; otherwise the most
-    cubic factorisation with px >= py >= pz."""
+    """1 -> 1x1x1, 2 -> 1x1x2, 4 -> 1x2x2, 8 -> 2x2x2; otherwise the most cubic factorisation with
+    pz >= py >= px.  z is split first: z faces are contiguous in memory, and as long as x is not split
+    the fused row pass needs no x-face exchange + column fix-up between its two i-colours."""
     best = None
     for pz in range(1, world + 1):
         if world % pz:
@@ -68,7 +69,7 @@ def rank_grid(world):
             key = (px - pz, px)
             if best is None or key < best[0]:
                 best = (key, (px, py, pz))
-    return best[1]
+    return best[1][::-1]
 
 
 class Topology:
@@ -102,118 +103,127 @@ class Topology:
 
 
 # ------------------------------------------------------------------ halo exchange
-def _sl(d, n, recv):
-    """slice along one axis of extent n+2 for offset d: send = owned cells next to that side,
-    recv = ghost cells on that side"""
+def _rng(d, n, recv, has_minus, has_plus):
+    """index range (start, stop) along one axis of extent n+2 for neighbour offset d.
+    d != 0: send = the owned layer next to that side, recv = the ghost layer on that side.
+    d == 0 (tangential): the owned cells, plus the ghost cell on every side that is a PHYSICAL
+    boundary -- those ghosts hold values the serial kernels compute there for even extents
+    (IICF1 = IIC) and must stay coherent across ranks; a ghost on a side with a neighbouring rank
+    belongs to the diagonal neighbour's message, so the boxes of one exchange never overlap."""
     if d == 0:
-        # tangential directions travel with their ghost cells: physical-boundary ghosts hold values
-        # the serial kernels compute there for even extents (IICF1 = IIC) and must stay coherent
-        # across ranks; ghosts owned by a diagonal neighbour are overwritten by that neighbour's
-        # message, which is unpacked later (faces, then edges, then corners)
-        return slice(0, n + 2)
+        return (1 if has_minus else 0, n + 1 if has_plus else n + 2)
     if d < 0:
-        return slice(0, 1) if recv else slice(1, 2)
-    return slice(n + 1, n + 2) if recv else slice(n, n + 1)
+        return (0, 1) if recv else (1, 2)
+    return (n + 1, n + 2) if recv else (n, n + 1)
 
 
 class Halo:
-    def __init__(self, topo, n, device, staged):
-        """n = (nx,ny,nz) local interior extents"""
+    """ghost-layer exchange with the (up to 26) neighbouring ranks: pack -> grouped isend/irecv ->
+    unpack.  Packing is one kernel launch through the C ABI when the backend offers `box_copy`
+    (GPU), torch slicing otherwise (CPU tests)."""
+
+    def __init__(self, topo, n, device, staged, backend=None):
         self.topo, self.n, self.device, self.staged = topo, n, device, staged
-        self.nb = []
-        for (dx, dy, dz), peer in sorted(topo.neighbours().items(), key=lambda kv: (sum(map(abs, kv[0])), kv[0])):
-            send = (_sl(dz, n[2], False), _sl(dy, n[1], False), _sl(dx, n[0], False))
-            recv = (_sl(dz, n[2], True), _sl(dy, n[1], True), _sl(dx, n[0], True))
-            self.nb.append(((dx, dy, dz), peer, send, recv))
+        self.be = backend if hasattr(backend, "box_copy") else None
+        self.nb = []  # (offset, peer, send box, recv box, size, buffer offset); box = (i0,j0,k0,ni,nj,nk)
+        off = 0
+        hm = [topo.has(d, -1) for d in range(3)]
+        hp = [topo.has(d, +1) for d in range(3)]
+        for o, peer in sorted(topo.neighbours().items()):
+            sr = [_rng(o[d], n[d], False, hm[d], hp[d]) for d in range(3)]
+            rr = [_rng(o[d], n[d], True, hm[d], hp[d]) for d in range(3)]
+            sbox = (sr[0][0], sr[1][0], sr[2][0], sr[0][1] - sr[0][0], sr[1][1] - sr[1][0], sr[2][1] - sr[2][0])
+            rbox = (rr[0][0], rr[1][0], rr[2][0], rr[0][1] - rr[0][0], rr[1][1] - rr[1][0], rr[2][1] - rr[2][0])
+            size = sbox[3] * sbox[4] * sbox[5]
+            self.nb.append((o, peer, sbox, rbox, size, off))
+            off += size
+        self.total = off
         self._buf = {}
+        if self.be is not None and self.nb:
+            IntArr, OffArr = C.c_int * (6 * len(self.nb)), C.c_ulonglong * len(self.nb)
+            self._sboxes = IntArr(*[v for e in self.nb for v in e[2]])
+            self._rboxes = IntArr(*[v for e in self.nb for v in e[3]])
+            self._offs = OffArr(*[e[5] for e in self.nb])
+        # x-face mini exchange (one box each way), see exchange_x
+        nx, ny, nz = n
+        self._xface = (1, 1, 1, 1, ny, nz)  # template: i0 is filled in per call
 
-    def _buffers(self, key, shape):
-        k = (key, tuple(shape))
-        if k not in self._buf:
-            mk = lambda: torch.empty(shape, dtype=torch.float64, device=self.device)
-            self._buf[k] = (mk(), mk())
-        return self._buf[k]
+    def _buffers(self, nplanes):
+        if nplanes not in self._buf:
+            mk = lambda: torch.empty(max(self.total, 1) * nplanes, dtype=torch.float64, device=self.device)
+            self._buf[nplanes] = (mk(), mk())
+        return self._buf[nplanes]
 
-    def _run(self, items):
-        """items: list of (peer, sendbuf, recvbuf)"""
-        if not items:
+    def _p2p(self, sends, recvs):
+        """sends/recvs: lists of (peer, 1-D contiguous tensor)"""
+        if not sends and not recvs:
             return
-        if self.staged:  # gloo with device tensors: stage through host memory
-            hs = [(p, s.cpu(), torch.empty(r.shape, dtype=r.dtype)) for p, s, r in items]
-            ops = []
-            for p, s, r in hs:
-                ops.append(dist.P2POp(dist.isend, s, p))
-                ops.append(dist.P2POp(dist.irecv, r, p))
+        if self.staged:  # gloo with device tensors (one-GPU rehearsal): stage through host memory
+            hs = [(p, t.cpu()) for p, t in sends]
+            hr = [(p, torch.empty(t.shape, dtype=t.dtype)) for p, t in recvs]
+            ops = [dist.P2POp(dist.isend, t, p) for p, t in hs] + [dist.P2POp(dist.irecv, t, p) for p, t in hr]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-            for (_, _, r), (_, _, hr) in zip(items, hs):
-                r.copy_(hr)
+            for (_, t), (_, h) in zip(recvs, hr):
+                t.copy_(h)
             return
-        ops = []
-        for p, s, r in items:
-            ops.append(dist.P2POp(dist.isend, s, p))
-            ops.append(dist.P2POp(dist.irecv, r, p))
+        ops = [dist.P2POp(dist.isend, t, p) for p, t in sends] + [dist.P2POp(dist.irecv, t, p) for p, t in recvs]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
+    @staticmethod
+    def _view(arr, box):
+        i0, j0, k0, ni, nj, nk = box
+        return arr[..., k0:k0 + nk, j0:j0 + nj, i0:i0 + ni]
+
     def exchange(self, arr):
         """fill every ghost cell that has an owner on another rank; arr: (..., KK, JJ, II)"""
-        items, post = [], []
-        for off, peer, send, recv in self.nb:
-            src = arr[(Ellipsis,) + send]
-            sb, rb = self._buffers(off, src.shape)
-            sb.copy_(src)
-            items.append((peer, sb, rb))
-            post.append((recv, rb))
-        self._run(items)
-        for recv, rb in post:
-            arr[(Ellipsis,) + recv].copy_(rb)
+        if not self.nb:
+            return
+        nplanes = 1
+        for v in arr.shape[:-3]:
+            nplanes *= int(v)
+        sb, rb = self._buffers(nplanes)
+        if self.be is not None:
+            self.be.box_copy(arr, nplanes, len(self.nb), self._sboxes, self._offs, sb, 0)
+        else:
+            for o, peer, sbox, rbox, size, off in self.nb:
+                sb[off * nplanes:(off + size) * nplanes].copy_(self._view(arr, sbox).reshape(-1))
+        sends = [(e[1], sb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in self.nb]
+        recvs = [(e[1], rb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in self.nb]
+        self._p2p(sends, recvs)
+        if self.be is not None:
+            self.be.box_copy(arr, nplanes, len(self.nb), self._rboxes, self._offs, rb, 1)
+        else:
+            for o, peer, sbox, rbox, size, off in self.nb:
+                v = self._view(arr, rbox)
+                v.copy_(rb[off * nplanes:(off + size) * nplanes].reshape(v.shape))
 
     def exchange_x(self, arr, to_minus):
-        """x faces only.  to_minus: send the first owned column to the -x neighbour and receive the
-        +x neighbour's into the high ghost column (UP order); else the mirror image (DOWN order)."""
+        """x faces only (owned j,k).  to_minus: send the first owned column to the -x neighbour and
+        receive the +x neighbour's into the high ghost column (UP order); else the mirror image."""
         nx, ny, nz = self.n
         t = self.topo
-        items, post = [], []
-        J, K = slice(1, ny + 1), slice(1, nz + 1)
         if to_minus:
             send_to, send_col, recv_from, recv_col = -1, 1, +1, nx + 1
         else:
             send_to, send_col, recv_from, recv_col = +1, nx, -1, 0
-        sb = rb = None
-        shape = (nz, ny, 1)
+        c = t.coord
+        key = ("x", to_minus)
+        if key not in self._buf:
+            mk = lambda: torch.empty(ny * nz, dtype=torch.float64, device=self.device)
+            self._buf[key] = (mk(), mk())
+        sb, rb = self._buf[key]
+        sends, recvs = [], []
         if t.has(0, send_to):
-            sb, _ = self._buffers(("xs", send_to), shape)
-            sb.copy_(arr[K, J, send_col:send_col + 1])
+            sb.copy_(arr[1:nz + 1, 1:ny + 1, send_col].reshape(-1))
+            sends.append((t.rank_of((c[0] + send_to, c[1], c[2])), sb))
         if t.has(0, recv_from):
-            _, rb = self._buffers(("xr", recv_from), shape)
-        c = list(t.coord)
-        if self.staged:
-            ops, hr = [], None
-            if sb is not None:
-                c2 = (c[0] + send_to, c[1], c[2])
-                ops.append(dist.P2POp(dist.isend, sb.cpu(), t.rank_of(c2)))
-            if rb is not None:
-                c2 = (c[0] + recv_from, c[1], c[2])
-                hr = torch.empty(shape, dtype=torch.float64)
-                ops.append(dist.P2POp(dist.irecv, hr, t.rank_of(c2)))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            if rb is not None:
-                rb.copy_(hr)
-        else:
-            ops = []
-            if sb is not None:
-                ops.append(dist.P2POp(dist.isend, sb, t.rank_of((c[0] + send_to, c[1], c[2]))))
-            if rb is not None:
-                ops.append(dist.P2POp(dist.irecv, rb, t.rank_of((c[0] + recv_from, c[1], c[2]))))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-        if rb is not None:
-            arr[K, J, recv_col:recv_col + 1].copy_(rb)
-        return rb is not None
+            recvs.append((t.rank_of((c[0] + recv_from, c[1], c[2])), rb))
+        self._p2p(sends, recvs)
+        if recvs:
+            arr[1:nz + 1, 1:ny + 1, recv_col].copy_(rb.reshape(nz, ny))
+        return bool(recvs)
 
 
 # ------------------------------------------------------------------ GPU backend
@@ -283,6 +293,11 @@ class GpuBackend:
                 capi.lib.cedar_amd_solver_vcycle(h.s.h, x.data_ptr(), b.data_ptr())
         return _H()
 
+    def box_copy(self, arr, nplanes, nboxes, boxes, offs, buf, unpack):
+        KK, JJ, II = arr.shape[-3:]
+        self.lib.cedar_amd_box_copy(self._p(arr), C.c_uint(II), C.c_uint(JJ), C.c_uint(KK), nplanes, nboxes,
+                                    boxes, offs, self._p(buf), unpack)
+
     def sumsq(self, r):
         v = self.capi.lib.cedar_amd_l2norm(r.data_ptr(), r.shape[2], r.shape[1], r.shape[0])
         return v * v
@@ -334,7 +349,7 @@ class DistSolver3:
                 if p[d] > 1 and l < self.la:
                     assert n[d] % 2 == 0, f"level {l}: local extent {n[d]} in dim {d} must be even"
             shp = (n[2] + 2, n[1] + 2, n[0] + 2)
-            L.halo = Halo(topo, n, A_local.device, staged)
+            L.halo = Halo(topo, n, A_local.device, staged, backend)
             L.res = backend.zeros(shp)
             L.sor = backend.zeros((2,) + shp)
             if l == 0:

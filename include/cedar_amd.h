@@ -152,6 +152,13 @@ void cedar_amd_setup_interp3_phase(real_t *so, real_t *ci, len_t iif, len_t jjf,
                                    len_t iic, len_t jjc, len_t kkc, int ifd, int nstncl, int phase,
                                    int ilo, int jlo, int klo);
 
+/* pack (unpack = 0) / unpack (1) up to 26 sub-boxes of a device array (nplanes x kk x jj x ii) to /
+ * from one contiguous device buffer in one launch: boxes = {i0,j0,k0,ni,nj,nk} per box (0-based incl.
+ * ghost), offsets[b] = start of box b in the buffer in doubles per plane (box b occupies
+ * offsets[b]*nplanes .. ).  Device pointers only. */
+void cedar_amd_box_copy(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, int nboxes,
+                        const int *boxes, const unsigned long long *offsets, real_t *buf, int unpack);
+
 /* ------------------------------------------------------------------ 2. handle API */
 typedef struct cedar_amd_solver cedar_amd_solver;
 

@@ -81,6 +81,7 @@ CASES = [
     ("poisson7", (8, 8, 8), (2, 1, 1), 2),
     ("rand27", (4, 4, 4), (2, 2, 2), 2),
     ("rand27", (8, 8, 8), (2, 2, 2), 32),
+    ("rand27", (6, 8, 8), (1, 2, 2), 2),
 ]
 
 
@@ -112,8 +113,8 @@ def test_distributed_equals_single_domain(case, tmp_path, oracle):
 
 def test_rank_grid_and_neighbours():
     from cedar_amd.dist import Topology, rank_grid
-    assert rank_grid(1) == (1, 1, 1) and rank_grid(2) == (2, 1, 1)
-    assert rank_grid(4) == (2, 2, 1) and rank_grid(8) == (2, 2, 2)
+    assert rank_grid(1) == (1, 1, 1) and rank_grid(2) == (1, 1, 2)
+    assert rank_grid(4) == (1, 2, 2) and rank_grid(8) == (2, 2, 2) and rank_grid(12) == (2, 2, 3)
     t = Topology(5, 8)  # coord (1,0,1): rank = k*4 + j*2 + i (src/3d/util/topo.cc:82-84)
     assert t.coord == (1, 0, 1)
     nb = t.neighbours()
