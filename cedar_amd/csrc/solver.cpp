@@ -151,9 +151,30 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	smooth(s, L, x, b, BMG_UP, s->st.nrelax_post, st);
 }
 
+// full-multigrid cycle, include/cedar/cycle/fcycle.h:49-83: restrict the right-hand side itself down
+// to the coarsest level, solve there, and on the way up interpolate (x = P x_c: interp_add onto
+// x = 0 with a zero "residual") and run one V-cycle from that level.
+void fmg_cycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_t st)
+{
+	if (lvl == (int)s->lv.size() - 1) {
+		coarse_solve(s, x, b, st);
+		return;
+	}
+	Level &L = s->lv[lvl], &K = s->lv[lvl + 1];
+	if (s->nd == 2) restrict2(b, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	else restrict3(b, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
+	fmg_cycle(s, lvl + 1, K.x, K.b, st);
+	CEDAR_HIP_CHECK(hipMemsetAsync(x, 0, L.npts * sizeof(real_t), st));
+	CEDAR_HIP_CHECK(hipMemsetAsync(L.res, 0, L.npts * sizeof(real_t), st));
+	if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
+	ncycle(s, lvl, x, b, st);
+}
+
 void cycle_launch(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 {
-	if (s->lv.size() == 1) coarse_solve(s, x, b, st); // vcycle.h:37-38
+	if (s->lv.size() == 1) coarse_solve(s, x, b, st); // vcycle.h:37-38, fcycle.h:42-43
+	else if (s->st.cycle == 1) fmg_cycle(s, 0, x, b, st);
 	else ncycle(s, 0, x, b, st);
 }
 
@@ -206,6 +227,7 @@ void cedar_amd_default_settings(cedar_amd_settings *s)
 	s->max_iter = 10;
 	s->tol = 1e-8;
 	s->min_coarse = 3;
+	s->cycle = 0;
 }
 
 cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil,

@@ -257,6 +257,7 @@ public:
 		st.nrelax_pre = settings.nrelax_pre; st.nrelax_post = settings.nrelax_post;
 		st.num_levels = settings.num_levels; st.max_iter = settings.maxiter; st.tol = settings.tol;
 		st.min_coarse = settings.min_coarse;
+		st.cycle = settings.cycle;
 		if (kman->get_params()->per_mask() != 0) log::error << "periodic boundaries are not implemented on the GPU path" << std::endl;
 		h = cedar_amd_solver_create(2, fop.shape(0), fop.shape(1), 1, stencil_ndirs<fsten>::value, fop.data(), 0, &st);
 	}

@@ -205,6 +205,7 @@ public:
 		st.nrelax_pre = settings.nrelax_pre; st.nrelax_post = settings.nrelax_post;
 		st.num_levels = settings.num_levels; st.max_iter = settings.maxiter; st.tol = settings.tol;
 		st.min_coarse = settings.min_coarse;
+		st.cycle = settings.cycle;
 		if (settings.relaxation != ml_settings::relax_type::point)
 			log::error << "3D: only point relaxation is implemented on the GPU path" << std::endl;
 		h = cedar_amd_solver_create(3, fop.shape(0), fop.shape(1), fop.shape(2), stencil_ndirs<fsten>::value, fop.data(), 0, &st);

@@ -107,6 +107,7 @@ struct ml_settings {
 	enum class relax_type { point, line_x, line_y, line_xy };
 	relax_type relaxation = relax_type::point;
 	int nrelax_pre = 2, nrelax_post = 1, num_levels = -1, maxiter = 10, min_coarse = 3;
+	int cycle = 0; // 0 = v, 1 = f
 	real_t tol = 1e-8;
 	void init(config & conf)
 	{
@@ -117,7 +118,9 @@ struct ml_settings {
 		else if (r == "line-xy") relaxation = relax_type::line_xy;
 		else log::error << "invalid relaxation type: " << r << std::endl;
 		auto cyc = conf.get<std::string>("solver.cycle.type", "v");
-		if (cyc != "v") log::error << "only V cycles are implemented on the GPU path (got " << cyc << ")" << std::endl;
+		if (cyc == "v") cycle = 0;
+		else if (cyc == "f") cycle = 1;
+		else log::error << "invalid cycle type: " << cyc << std::endl;
 		nrelax_pre = conf.get<int>("solver.cycle.nrelax-pre", 2);
 		nrelax_post = conf.get<int>("solver.cycle.nrelax-post", 1);
 		num_levels = conf.get<int>("solver.num-levels", -1);

@@ -173,6 +173,7 @@ typedef struct {
 	int max_iter;     /* solver.max-iter (10) :41 */
 	double tol;       /* solver.tol (1e-8) :42 */
 	int min_coarse;   /* solver.min_coarse (3) :43 */
+	int cycle;        /* solver.cycle.type: 0 = "v" (default), 1 = "f" (include/cedar/cycle/fcycle.h:49-83) :30-36 */
 } cedar_amd_settings;
 
 void cedar_amd_default_settings(cedar_amd_settings *s);

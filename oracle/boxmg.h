@@ -123,7 +123,8 @@ int orc_ml_nlevels(const orc_ml *ml);
 void orc_ml_level_dims(const orc_ml *ml, int lvl, len_t *nx, len_t *ny, len_t *nz);
 /* raw access to a level's arrays for parity tests: what = "A","P","SOR0","SOR1","ABD" */
 const real_t *orc_ml_level_array(const orc_ml *ml, int lvl, const char *what, size_t *len);
-void orc_ml_vcycle(orc_ml *ml, real_t *x, const real_t *b);
+void orc_ml_set_cycle(orc_ml *ml, int cycle); /* 0 = V (default), 1 = F (fcycle.h) */
+void orc_ml_vcycle(orc_ml *ml, real_t *x, const real_t *b); /* cycle->run(x, b) */
 /* multilevel::solve: returns the number of cycles run; rel[0] = initial ||r||_2,
  * rel[1..] = ||r_i||_2 / ||r_0||_2 after each cycle */
 int orc_ml_solve(orc_ml *ml, const real_t *b, real_t *x, int maxiter, real_t tol, real_t *rel);

@@ -38,8 +38,8 @@ def seq_l2(v):
 class RefML:
     """multilevel::setup + vcycle + solve composed from the Fortran kernels."""
 
-    def __init__(self, R, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3):
-        self.R, self.relax, self.pre, self.post = R, relax, nrelax_pre, nrelax_post
+    def __init__(self, R, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, cycle="v"):
+        self.R, self.relax, self.pre, self.post, self.cycle = R, relax, nrelax_pre, nrelax_post, cycle
         self.nd = nd = so.ndim - 1
         n = [s - 2 for s in so.shape[1:]][::-1]  # nx, ny[, nz]
         ng = 0
@@ -124,9 +124,28 @@ class RefML:
             R.interp_add3(x, cx, self.A[l], self.res[l], Pm)
         self._smooth(l, x, b, UP, self.post)
 
+    def _fmg(self, l, x, b):
+        """include/cedar/cycle/fcycle.h:49-83"""
+        R = self.R
+        if l == self.nlev - 1:
+            (R.solve_cg2 if self.nd == 2 else R.solve_cg3)(x, b, self.abd)
+            return
+        cx, cb, Pm = self.x[l + 1], self.b[l + 1], self.P[l + 1]
+        (R.restrict2 if self.nd == 2 else R.restrict3)(b, cb, Pm)
+        self._fmg(l + 1, cx, cb)
+        x[...] = 0.0
+        self.res[l][...] = 0.0
+        if self.nd == 2:
+            R.interp_add2(x, cx, self.res[l], self.A[l], Pm)
+        else:
+            R.interp_add3(x, cx, self.A[l], self.res[l], Pm)
+        self._cycle(l, x, b)
+
     def vcycle(self, x, b):
         if self.nlev == 1:
             (self.R.solve_cg2 if self.nd == 2 else self.R.solve_cg3)(x, b, self.abd)
+        elif self.cycle == "f":
+            self._fmg(0, x, b)
         else:
             self._cycle(0, x, b)
 

@@ -24,7 +24,7 @@ typedef struct {
 } orc_level;
 
 struct orc_ml {
-	int nd, nlev, relax, nrelax_pre, nrelax_post;
+	int nd, nlev, relax, nrelax_pre, nrelax_post, cycle;
 	orc_level *lv;
 	real_t *ABD, *bbd;
 	len_t nabd1, nabd2;
@@ -208,9 +208,30 @@ static void ncycle(orc_ml *ml, int lvl, real_t *x, const real_t *b)
 	smooth(ml, L, x, b, BMG_UP, ml->nrelax_post);
 }
 
+/* include/cedar/cycle/fcycle.h:49-83 */
+static void fmg_cycle(orc_ml *ml, int lvl, real_t *x, const real_t *b)
+{
+	if (lvl == ml->nlev - 1) {
+		coarse_solve(ml, x, b);
+		return;
+	}
+	orc_level *L = &ml->lv[lvl], *K = &ml->lv[lvl + 1];
+	if (ml->nd == 2) orc2_restrict(b, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
+	else orc3_restrict(b, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK);
+	fmg_cycle(ml, lvl + 1, K->x, K->b);
+	memset(x, 0, L->npts * sizeof(real_t));
+	memset(L->res, 0, L->npts * sizeof(real_t));
+	if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
+	else orc3_interp_add(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK);
+	ncycle(ml, lvl, x, b);
+}
+
+void orc_ml_set_cycle(orc_ml *ml, int cycle) { ml->cycle = cycle; }
+
 void orc_ml_vcycle(orc_ml *ml, real_t *x, const real_t *b)
 {
 	if (ml->nlev == 1) coarse_solve(ml, x, b); /* vcycle.h:37-38 */
+	else if (ml->cycle == 1) fmg_cycle(ml, 0, x, b);
 	else ncycle(ml, 0, x, b);
 }
 

@@ -182,6 +182,11 @@ SOLVES = {
                         dict(relax="point", nrelax_pre=2, nrelax_post=1)),
     "poisson7_64_v21": (lambda: pb.poisson3(64, 64, 64), lambda: pb.rhs3(64, 64, 64),
                         dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    # F-cycles (include/cedar/cycle/fcycle.h), SURVEY section 8f-3
+    "varcoef9_200x120_f21": (lambda: pb.varcoef9(200, 120), lambda: pb.rhs2(200, 120),
+                             dict(relax="point", nrelax_pre=2, nrelax_post=1, cycle="f")),
+    "fe27_40x33x50_f21": (lambda: pb.fe3(40, 33, 50), lambda: pb.rhs3(40, 33, 50),
+                          dict(relax="point", nrelax_pre=2, nrelax_post=1, cycle="f")),
 }
 
 # absolute floor (in units of ||r0||) below which residual histories of two
