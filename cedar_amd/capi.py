@@ -16,6 +16,12 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, "lib", "libcedar_amd.so")
 if not os.path.exists(LIBPATH):
+    # not built yet (fresh checkout): compile the HIP sources in-tree; still no CPU fallback
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.call(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")])
+if not os.path.exists(LIBPATH):
     raise ImportError(
         f"{LIBPATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950); cedar_amd has no CPU fallback")

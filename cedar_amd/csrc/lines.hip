@@ -12,10 +12,11 @@
 //
 // Relaxation (hot path, 64 algorithmic B/DOF per direction): all lines of one
 // colour are independent.  One workgroup owns one line held in LDS (<= 64 KB);
-// both DPTTRS sweeps are first-order affine recurrences y_i = a_i y_{i-1} + c_i,
-// evaluated tile by tile (BS consecutive unknowns) with a Kogge-Stone scan of
-// the affine maps over wavefront shuffles, a 4-entry cross-wave fix-up in LDS
-// and a scalar carry between tiles.  The scan re-associates the recurrence, so
+// both DPTTRS sweeps are first-order affine recurrences y_i = a_i y_{i-1} + c_i.
+// Every lane owns 8 consecutive unknowns (sequential, reference order); the
+// lanes' composite maps are combined with a Kogge-Stone scan over wavefront
+// shuffles, a 4-entry cross-wave fix-up in LDS and a scalar carry between
+// tiles of 2048 unknowns.  The scan re-associates the recurrence, so
 // results agree with the sequential DPTTRS to rounding (like one vendor LAPACK
 // against another), not bit-for-bit; tolerances are stated in tests/.
 // y-lines are strided in memory: their right-hand sides are gathered through
@@ -81,10 +82,18 @@ void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st
 }
 
 // ------------------------------------------------------------------ affine scan
-// inclusive scan over the workgroup of the maps y -> a*y + c (element order = thread order);
-// returns the value of this thread's unknown given the carry entering the tile.
+// Every lane owns CH consecutive unknowns of the line.  A sweep over a tile of BS*CH unknowns is
+//   (1) lane-local: compose the CH maps  y -> a*y + c  of the chunk            (sequential, exact order)
+//   (2) workgroup scan of the BS composites: Kogge-Stone over wavefront shuffles, cross-wave fix-up
+//       through LDS, scalar carry from the previous tile
+//   (3) lane-local: re-run the chunk from the value entering it.
+// Only step (2) re-associates the recurrence.
+constexpr int CH = 8;
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 3); } // LDS index: one pad per 8 -> stride-9 chunks, no bank conflicts
+
 template <int BS>
-__device__ __forceinline__ real_t affine_tile(real_t a, real_t c, real_t carry, real_t *wa, real_t *wc)
+__device__ __forceinline__ void affine_scan(real_t a, real_t c, real_t carry, real_t *wa, real_t *wc,
+                                            real_t &y_in, real_t &y_last)
 {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -95,6 +104,8 @@ __device__ __forceinline__ real_t affine_tile(real_t a, real_t c, real_t carry, 
 			a = a * ap;
 		}
 	}
+	real_t ae = __shfl_up(a, 1, 64), ce = __shfl_up(c, 1, 64); // composite of the lanes before this one
+	if (lane == 0) { ae = 1.0; ce = 0.0; }
 	constexpr int NW = BS / 64;
 	if (NW > 1) {
 		if (lane == 63) { wa[w] = a; wc[w] = c; }
@@ -103,48 +114,71 @@ __device__ __forceinline__ real_t affine_tile(real_t a, real_t c, real_t carry, 
 		for (int u = 0; u < w; u++) y = wa[u] * y + wc[u];
 		carry = y;
 	}
-	return a * carry + c;
+	y_in = ae * carry + ce;
+	y_last = a * carry + c;
 }
 
-// Solve L D L^T x = y for the line held in LDS `y[0..n)`; d[0..n), e[0..n-1) contiguous in HBM.
+// Solve L D L^T x = y for the line held in LDS (padded index lpad(i)); d[0..n), e[0..n-1) in HBM.
 template <int BS>
 __device__ __forceinline__ void line_pttrs(real_t *y, int n, const real_t *__restrict__ d, const real_t *__restrict__ e,
                                            real_t *wa, real_t *wc, real_t *carry_slot)
 {
 	// forward: y_i = y_i - e_{i-1} y_{i-1}
 	real_t carry = 0.0;
-	for (int base = 0; base < n; base += BS) {
-		const int i = base + threadIdx.x;
-		real_t a = 0.0, c = 0.0;
-		if (i < n) {
-			c = y[i];
-			a = i > 0 ? -e[i - 1] : 0.0;
+	for (int base = 0; base < n; base += BS * CH) {
+		const int i0 = base + (int)threadIdx.x * CH;
+		real_t a[CH], c[CH];
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			const int i = i0 + m;
+			if (i < n) { c[m] = y[lpad(i)]; a[m] = i > 0 ? -e[i - 1] : 0.0; }
+			else { c[m] = 0.0; a[m] = 0.0; }
 		}
-		const real_t v = affine_tile<BS>(a, c, carry, wa, wc);
-		if (i < n) y[i] = v;
-		if (threadIdx.x == BS - 1) *carry_slot = v;
+		real_t A = 1.0, Cc = 0.0;
+#pragma unroll
+		for (int m = 0; m < CH; m++) { Cc = a[m] * Cc + c[m]; A = a[m] * A; }
+		real_t v, last;
+		affine_scan<BS>(A, Cc, carry, wa, wc, v, last);
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			v = a[m] * v + c[m];
+			if (i0 + m < n) y[lpad(i0 + m)] = v;
+		}
+		if (threadIdx.x == BS - 1) *carry_slot = last;
 		__syncthreads();
 		carry = *carry_slot;
 		__syncthreads();
 	}
-	// backward: x_i = y_i/d_i - e_i x_{i+1}, i = n-1 .. 0 (thread order = reversed index)
+	// backward: x_i = y_i/d_i - e_i x_{i+1}; reversed position r <-> i = n-1-r
 	carry = 0.0;
-	for (int base = 0; base < n; base += BS) {
-		const int r = base + threadIdx.x; // reversed position
-		const int i = n - 1 - r;
-		real_t a = 0.0, c = 0.0;
-		if (r < n) {
-			c = y[i] / d[i];
-			a = r > 0 ? -e[i] : 0.0;
+	for (int base = 0; base < n; base += BS * CH) {
+		const int r0 = base + (int)threadIdx.x * CH;
+		real_t a[CH], c[CH];
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			const int r = r0 + m, i = n - 1 - r;
+			if (r < n) { c[m] = y[lpad(i)] / d[i]; a[m] = r > 0 ? -e[i] : 0.0; }
+			else { c[m] = 0.0; a[m] = 0.0; }
 		}
-		const real_t v = affine_tile<BS>(a, c, carry, wa, wc);
-		if (r < n) y[i] = v;
-		if (threadIdx.x == BS - 1) *carry_slot = v;
+		real_t A = 1.0, Cc = 0.0;
+#pragma unroll
+		for (int m = 0; m < CH; m++) { Cc = a[m] * Cc + c[m]; A = a[m] * A; }
+		real_t v, last;
+		affine_scan<BS>(A, Cc, carry, wa, wc, v, last);
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			v = a[m] * v + c[m];
+			if (r0 + m < n) y[lpad(n - 1 - r0 - m)] = v;
+		}
+		if (threadIdx.x == BS - 1) *carry_slot = last;
 		__syncthreads();
 		carry = *carry_slot;
 		__syncthreads();
 	}
 }
+
+// doubles of LDS a line of n unknowns needs (padded line + scan scratch)
+static inline size_t line_lds_doubles(int n) { return (size_t)n + (size_t)(n >> 3) + 24; }
 
 // ------------------------------------------------------------------ x-lines
 template <int BS, bool NINE>
@@ -153,7 +187,8 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
                                                             int II, int JJ, int jb, int nlines)
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
-	real_t *y = lds, *wa = lds + (II - 2), *wc = wa + 4, *cs = wc + 4;
+	const int npad = (II - 2) + ((II - 2) >> 3) + 1;
+	real_t *y = lds, *wa = lds + npad, *wc = wa + 4, *cs = wc + 4;
 	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nlines);
 	if (L >= (unsigned)nlines) return;
 	const size_t sj = II, PS = (size_t)II * JJ;
@@ -171,16 +206,16 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 			s = s + so[KNW * PS + x + sj] * q[x - 1 + sj];
 			s = s + so[KSW * PS + x + 1 + sj] * q[x + 1 + sj];
 		}
-		y[t] = s;
+		y[lpad(t)] = s;
 	}
 	__syncthreads();
 	line_pttrs<BS>(y, n, sor + row + 1, sor + PS + row + 2, wa, wc, cs);
-	for (int t = threadIdx.x; t < n; t += BS) q[row + 1 + t] = y[t];
+	for (int t = threadIdx.x; t < n; t += BS) q[row + 1 + t] = y[lpad(t)];
 }
 
 static bool lds_ok(int n, const char *who)
 {
-	if ((size_t)(n + 16) * sizeof(real_t) > 160 * 1024 - 512) {
+	if (line_lds_doubles(n) * sizeof(real_t) > 160 * 1024 - 512) {
 		fprintf(stderr, "[cedar_amd] %s: line of %d unknowns does not fit the 160 KB LDS\n", who, n);
 		abort();
 	}
@@ -193,7 +228,7 @@ static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t
 {
 	int nlines = (JJ - 2 - jb + 1) / 2;
 	if (nlines <= 0) return;
-	size_t shm = (size_t)(II - 2 + 16) * sizeof(real_t);
+	size_t shm = line_lds_doubles(II - 2) * sizeof(real_t);
 	if (nstncl == 5) {
 		auto k = relax_lines_x_kernel<BS, true>;
 		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -213,7 +248,7 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	for (int c = 0; c < 2; c++) {
 		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
 		int jb = (updown == BMG_DOWN) ? 1 - c : c;
-		if (II - 2 <= 64) launch_x<64>(so, qf, q, sor, II, JJ, nstncl, jb, st);
+		if (II - 2 <= 512) launch_x<64>(so, qf, q, sor, II, JJ, nstncl, jb, st);
 		else launch_x<256>(so, qf, q, sor, II, JJ, nstncl, jb, st);
 	}
 }
@@ -260,17 +295,18 @@ __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, cons
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int n = JJ - 2;
-	real_t *y = lds, *wa = lds + n, *wc = wa + 4, *cs = wc + 4;
+	const int npad = n + (n >> 3) + 1;
+	real_t *y = lds, *wa = lds + npad, *wc = wa + 4, *cs = wc + 4;
 	const unsigned L = blockIdx.x;
 	if (L >= (unsigned)nlines) return;
 	const size_t PS = (size_t)II * JJ;
 	const int i = 1 + ib + 2 * (int)L; // 0-based line position
 	real_t *line = bt + (size_t)L * ldt;
-	for (int t = threadIdx.x; t < n; t += BS) y[t] = line[t];
+	for (int t = threadIdx.x; t < n; t += BS) y[lpad(t)] = line[t];
 	__syncthreads();
 	// SOR(JJ,II,2): d = SOR(2.., i) , e = SOR(3.., i, 2)
 	line_pttrs<BS>(y, n, sor + (size_t)JJ * i + 1, sor + PS + (size_t)JJ * i + 2, wa, wc, cs);
-	for (int t = threadIdx.x; t < n; t += BS) line[t] = y[t];
+	for (int t = threadIdx.x; t < n; t += BS) line[t] = y[lpad(t)];
 }
 
 __global__ __launch_bounds__(256) void ylines_scatter_T(const real_t *__restrict__ bt, real_t *__restrict__ q,
@@ -303,7 +339,7 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	lds_ok(JJ - 2, "relax_lines_y");
 	const int n = JJ - 2;
 	const int ldt = (n + 15) & ~15;
-	const size_t shm = (size_t)(n + 16) * sizeof(real_t);
+	const size_t shm = line_lds_doubles(n) * sizeof(real_t);
 	for (int c = 0; c < 2; c++) {
 		int ib = (updown == BMG_DOWN) ? 1 - c : c; // DOWN: I = 3,5,.. first
 		int nlines = (II - 2 - ib + 1) / 2;
@@ -313,7 +349,7 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 			hipLaunchKernelGGL(ylines_rhs_T<true>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
 		else
 			hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
-		if (n <= 64) {
+		if (n <= 512) {
 			hipLaunchKernelGGL(ylines_solve<64>, dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt);
 		} else {
 			auto k = ylines_solve<256>;

@@ -64,7 +64,9 @@ def test_reference_style_sweeps(K, golden):
 # larger / ragged shapes against the oracle (no golden): odd and even extents, rows longer
 # than one workgroup pass, extents that exercise every fast-path width of the row kernels
 EXTRA_2D = [("x_300x7_9", 300, 7, 5), ("x_1030x5_9", 1030, 5, 5), ("x_129x130_5", 129, 130, 3),
-            ("x_3x3_9", 3, 3, 5), ("x_4x9_5", 4, 9, 3)]
+            ("x_3x3_9", 3, 3, 5), ("x_4x9_5", 4, 9, 3),
+            # lines longer than one scan tile (2048 unknowns) and than one wavefront tile (512)
+            ("x_4500x6_9", 4500, 6, 5), ("x_5x2300_9", 5, 2300, 5), ("x_600x7_5", 600, 7, 3)]
 EXTRA_3D = [("x_70x9x8_27", 70, 9, 8, 14), ("x_130x6x7_27", 130, 6, 7, 14), ("x_258x5x6_27", 258, 5, 6, 14),
             ("x_33x34x35_7", 33, 34, 35, 4), ("x_3x3x3_27", 3, 3, 3, 14), ("x_4x5x3_7", 4, 5, 3, 4)]
 
