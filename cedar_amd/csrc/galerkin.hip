@@ -195,10 +195,25 @@ __global__ __launch_bounds__(256) void galerkin3_kernel(const real_t *__restrict
 	    = (s == KP) ? acc : -acc;
 }
 
+#define G3PART(n) void galerkin3_part##n(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF, \
+                                        int IIC, int JJC, int KKC, int ifd, hipStream_t st);
+G3PART(0) G3PART(1) G3PART(2) G3PART(3)
+#undef G3PART
+
 void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                int IIC, int JJC, int KKC, int ifd, hipStream_t st)
 {
 	if (IIC < 3 || JJC < 3 || KKC < 3) return;
+	// default: compile-time specialised kernels (galerkin3_unrolled.inc); the table-driven kernel below
+	// is the readable statement of the same sum and stays selectable for cross-checks
+	static const bool generic = getenv("CEDAR_AMD_GALERKIN_GENERIC") && atoi(getenv("CEDAR_AMD_GALERKIN_GENERIC")) != 0;
+	if (!generic) {
+		galerkin3_part0(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
+		galerkin3_part1(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
+		galerkin3_part2(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
+		galerkin3_part3(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
+		return;
+	}
 	static bool ready = false;
 	if (!ready) {
 		signed char tab[3][3][3][4];

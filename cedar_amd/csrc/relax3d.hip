@@ -162,8 +162,23 @@ __device__ __forceinline__ void ldpair(const real_t *__restrict__ p, bool two, r
 	}
 }
 
+// operator rows are used by exactly one workgroup of a launch: stream them past the caches
+// (non-temporal) so that the q rows, which neighbouring workgroups share, stay resident
+template <bool NT>
+__device__ __forceinline__ void ldpair_so(const real_t *__restrict__ p, bool two, real_t &a, real_t &b)
+{
+	if (!NT) { ldpair(p, two, a, b); return; }
+	if (two) {
+		d2u v = __builtin_nontemporal_load(reinterpret_cast<const d2u *>(p));
+		a = v.x; b = v.y;
+	} else {
+		a = __builtin_nontemporal_load(p); b = 0.0;
+	}
+}
+
 // all operands of the pair (ie, io) of one row: 26 coefficients per point, qf, and the 3x3 q rows
 // (offsets ie-1 .. io+1); 16-byte loads, `two` = element io+1 is still inside the row
+template <bool NT>
 __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                             const real_t *__restrict__ q, size_t row, size_t sj, size_t sk, size_t PS,
                                             int ie, int io, bool two, C27 &ce, C27 &co,
@@ -173,7 +188,7 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 #define LD_I(slot, off, fe, fo)                                                        \
 {                                                                                  \
 	real_t a_, b_;                                                                 \
-	ldpair(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);               \
+	ldpair_so<NT>(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);        \
 	ce.fe = a_; co.fo = b_;                                                        \
 }
 	LD_I(KPW, 0, pw, pw) LD_I(KPS, 0, ps, ps) LD_I(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
@@ -186,7 +201,7 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 #define LD_IP(slot, off, f)                                                            \
 {                                                                                  \
 	real_t a_, b_;                                                                 \
-	ldpair(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);                \
+	ldpair_so<NT>(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);         \
 	ce.f = a_; co.f = b_;                                                          \
 }
 	LD_IP(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
@@ -215,7 +230,7 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 // fast path: one workgroup = one grid row, both i-colours.
 //   EFIRST = true : colour with even 1-based i (i = 2,4,..) first  (UP order)
 //   EFIRST = false: odd i first                                     (DOWN order)
-template <int BS, bool EFIRST>
+template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                     real_t *__restrict__ q, const real_t *__restrict__ sor,
                                                     int II, int JJ, int KK, int jb, int kb, int nrj, int nrk, TileShape ts,
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 	real_t qfe = 0, qfo = 0, sre = 0, sro = 0;
 
 	if (e_ok) {
-		load_pair27(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		load_pair27<NT>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
 		real_t a_, b_;
 		ldpair(sor + PS + row + ie, true, a_, b_); sre = a_; sro = b_;
 	}
@@ -310,7 +325,7 @@ __global__ void relax7_colour(const real_t *__restrict__ so, const real_t *__res
 // 27-point residual with the same lane layout as the relax row kernel: lane p owns the pair
 // (2p+1, 2p+2) of its row, every stream is read with 16-byte loads, one 16-byte store.
 // (BMG3_SymStd_residual.f90:77-104; bit-identical term order.)
-template <int BS>
+template <int BS, bool NT>
 __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                        const real_t *__restrict__ q, real_t *__restrict__ res,
                                                        int II, int JJ, int KK, unsigned nblk, TileShape ts)
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__
 		const bool o_ok = io <= II - 2, two = io + 1 <= II - 1;
 		C27 ce, co;
 		real_t qe[3][3][3], qo[3][3][3], qfe, qfo, de, dn;
-		load_pair27(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		load_pair27<NT>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
 		ldpair(so + row + ie, true, de, dn); // KP plane
 		const real_t re = offdiag27(qfe, ce, qe) - de * qe[1][1][1];
 		if (o_ok) {
@@ -343,9 +358,9 @@ void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t
 	const TileShape ts = tile_shape_resid();
 	unsigned nrows = tile_blocks((unsigned)(JJ - 2), (unsigned)(KK - 2), ts);
 	const int npairs = (II - 2 + 1) / 2;
-	if (npairs <= 64) hipLaunchKernelGGL(residual27_rows<64>, dim3(xcd_grid(nrows)), dim3(64), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
-	else if (npairs <= 128) hipLaunchKernelGGL(residual27_rows<128>, dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
-	else hipLaunchKernelGGL(residual27_rows<256>, dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+	if (npairs <= 64) hipLaunchKernelGGL((residual27_rows<64, false>), dim3(xcd_grid(nrows)), dim3(64), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+	else if (npairs <= 128) hipLaunchKernelGGL((residual27_rows<128, false>), dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+	else hipLaunchKernelGGL((residual27_rows<256, false>), dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 }
 
 static inline unsigned cap_grid(size_t n, unsigned bs)
@@ -366,10 +381,15 @@ static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t 
 	if (nrj <= 0 || nrk <= 0) return;
 	const TileShape ts = tile_shape_relax();
 	unsigned grid = xcd_grid(tile_blocks((unsigned)nrj, (unsigned)nrk, ts));
-	if (efirst)
-		hipLaunchKernelGGL((relax27_rows<BS, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
-	else
-		hipLaunchKernelGGL((relax27_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+	// non-temporal operator loads: measured -1.8 % per launch at 512^3 (profiles/r01_experiment_nt_loads.log)
+	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
+	if (efirst) {
+		if (nt) hipLaunchKernelGGL((relax27_rows<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+		else hipLaunchKernelGGL((relax27_rows<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+	} else {
+		if (nt) hipLaunchKernelGGL((relax27_rows<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+		else hipLaunchKernelGGL((relax27_rows<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+	}
 }
 
 // one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs
