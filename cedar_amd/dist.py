@@ -315,7 +315,7 @@ class DistSolver3:
     """cedar::cdr3::mpi::solver equivalent for Dirichlet problems, point relaxation, V(pre,post)."""
 
     def __init__(self, backend, topo, A_local, nrelax_pre=2, nrelax_post=1, min_coarse=3, max_iter=10, tol=1e-8,
-                 agglomerate_below=32):
+                 agglomerate_below=64):
         """A_local: (nst, nz+2, ny+2, nx+2) local part of the global operator (ghost layers are
         filled here by exchange; entries coupling to a neighbouring rank must be present)."""
         self.be, self.topo = backend, topo
