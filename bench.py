@@ -57,23 +57,22 @@ def build_problem(capi, wl, n):
     return capi.DeviceArray.from_numpy(so), capi.DeviceArray.from_numpy(b)
 
 
-def cpu_baseline(wl, relax):
-    """oracle on a bounded sample of the same workload, one host core"""
+def _cpu_sample(wl):
     import problems as pb
-    from pyoracle import Oracle
-    O = Oracle()
     if wl == "3d27":
-        n, so, b = 96, pb.fe3(96, 96, 96), pb.rhs3(96, 96, 96)
-        sample = "27-pt gallery::fe 96^3"
-    elif wl == "2d9":
-        n, so, b = 1024, pb.varcoef9(1024, 1024), pb.rhs2(1024, 1024)
-        sample = "9-pt variable-coefficient 1024^2"
-    elif wl == "2d9l":
-        n, so, b = 1024, pb.aniso9(1024, 1024), pb.rhs2(1024, 1024)
-        sample = "9-pt anisotropic 1024^2 line-xy"
-    else:
-        n, so, b = 512, pb.poisson2(512, 512), pb.rhs2(512, 512)
-        sample = "5-pt Poisson 512^2"
+        return pb.fe3(96, 96, 96), pb.rhs3(96, 96, 96), "27-pt gallery::fe 96^3"
+    if wl == "2d9":
+        return pb.varcoef9(1024, 1024), pb.rhs2(1024, 1024), "9-pt variable-coefficient 1024^2"
+    if wl == "2d9l":
+        return pb.aniso9(1024, 1024), pb.rhs2(1024, 1024), "9-pt anisotropic 1024^2 line-xy"
+    return pb.poisson2(512, 512), pb.rhs2(512, 512), "5-pt Poisson 512^2"
+
+
+def cpu_worker(wl, relax, seconds):
+    """one CPU rank: V(2,1) cycles on the bounded sample for `seconds`; prints one JSON line.
+    Touches no GPU (runs in its own process, started by cpu_baseline)."""
+    from pyoracle import Oracle
+    so, b, sample = _cpu_sample(wl)
     dof = float(np.prod([s - 2 for s in b.shape]))
     # preferred: the reference's own Fortran kernels (oracle/_ref, built in the build container and
     # shipped with the snapshot), chained in the reference's cycle order; fallback: the C restatement
@@ -84,7 +83,7 @@ def cpu_baseline(wl, relax):
         ml = RefML(Ref(), so, relax=relax, nrelax_pre=2, nrelax_post=1)
         kind, what = "reference", "oracle/_ref/libcedar_ref.so (reference Fortran, flang -O2, MKL LAPACK)"
     except Exception:
-        h = O.ml_create(so, relax=relax)
+        h = Oracle().ml_create(so, relax=relax)
         ml, closer = h, h.close
     x = np.zeros_like(b)
     ml.vcycle(x, b)  # warm-up
@@ -93,15 +92,50 @@ def cpu_baseline(wl, relax):
         ml.vcycle(x, b)
         cycles += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or cycles >= 40:
+        if dt > seconds or cycles >= 400:
             break
     if closer:
         closer()
-    return {"value": dof * cycles / dt, "unit": "DOF/s", "cores": 1, "kind": kind,
-            "sample": f"{sample}, {cycles} V(2,1) cycles, 1 thread, {what}"}
+    print(json.dumps({"dof_per_s": dof * cycles / dt, "cycles": cycles, "kind": kind, "what": what, "sample": sample}), flush=True)
+
+
+def cpu_baseline(wl, relax):
+    """The reference's CPU path beside the GPU number: the reference is single-threaded
+    per process and parallel only through MPI ranks, so (i) one rank on one core and (ii) one rank
+    per host core, each on its own block of the bounded sample (weak, halo traffic not charged:
+    an upper bound for the CPU).  Workers are child processes; they never touch the GPU."""
+    import subprocess
+
+    def launch(nproc, seconds):
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", wl, relax, str(seconds)]
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True) for _ in range(nproc)]
+        outs = []
+        for p in ps:
+            o, _ = p.communicate(timeout=600)
+            if p.returncode != 0:
+                raise RuntimeError("cpu worker failed")
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        return outs
+
+    one = launch(1, 8.0)[0]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    allc = launch(cores, 8.0) if cores > 1 else [one]
+    total = sum(o["dof_per_s"] for o in allc)
+    return {"value": total, "unit": "DOF/s", "cores": cores, "kind": one["kind"],
+            "single_core_value": one["dof_per_s"],
+            "sample": f"{one['sample']} per rank, V(2,1) cycles for 8 s, {cores} independent single-threaded ranks "
+                      f"(one per host core, no halo cost charged); single rank alone: {one['dof_per_s']:.3e} DOF/s; {one['what']}"}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2], sys.argv[3], float(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

@@ -142,6 +142,20 @@ void cedar_amd_sync(void) { CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream(
 void cedar_amd_set_stream(void *s) { cedar_amd::g_stream = static_cast<hipStream_t>(s); }
 void *cedar_amd_get_stream(void) { return cedar_amd::g_stream; }
 
+void cedar_amd_matvec2(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, int nstncl)
+{
+	const size_t P = (size_t)II * JJ;
+	Staged sso(so, P * nstncl, true, false), sq(q, P, true, false), sqf(qf, P, true, true);
+	matvec2(sso.get(), sq.get(), sqf.get(), (int)II, (int)JJ, nstncl, current_stream());
+}
+
+void cedar_amd_matvec3(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, len_t KK, int nstncl)
+{
+	const size_t P = (size_t)II * JJ * KK;
+	Staged sso(so, P * nstncl, true, false), sq(q, P, true, false), sqf(qf, P, true, true);
+	matvec3(sso.get(), sq.get(), sqf.get(), (int)II, (int)JJ, (int)KK, nstncl, current_stream());
+}
+
 double cedar_amd_l2norm(const real_t *v, len_t II, len_t JJ, len_t KK)
 {
 	size_t n = (size_t)II * JJ * KK;

@@ -66,6 +66,9 @@ void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int nstncl, hipStream_t st);
 void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int KK, int nstncl, hipStream_t st);
+// qf = A q (operator application with Cedar's sign convention), residual.hip
+void matvec2(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int nstncl, hipStream_t st);
+void matvec3(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int KK, int nstncl, hipStream_t st);
 // sum of squares over the interior -> *out (deterministic two-stage tree); scratch >= 4096 doubles
 void sumsq_interior(const real_t *v, int II, int JJ, int KK, real_t *scratch, real_t *out, hipStream_t st);
 // transfer.hip

@@ -12,7 +12,10 @@
 
 namespace cedar_amd {
 
-template <bool NINE>
+// MV = true turns the kernel into the operator application qf = A q of
+// BMG2_SymStd_UTILS_matvec (src/2d/ftn/mpi/BMG2_SymStd_UTILS_matvec.f90:84-118): diagonal term first,
+// then the same neighbour sequence subtracted; `res` receives A q and `qf` is not read.
+template <bool NINE, bool MV = false>
 __global__ __launch_bounds__(256) void residual2_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                          const real_t *__restrict__ q, real_t *__restrict__ res,
                                                          int II, int JJ)
@@ -22,6 +25,21 @@ __global__ __launch_bounds__(256) void residual2_kernel(const real_t *__restrict
 	if (i > II - 2) return;
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const size_t x = (size_t)i + sj * (size_t)j;
+	if (MV) {
+		real_t s = so[KO * PS + x] * q[x];
+		s = s - so[KW * PS + x] * q[x - 1];
+		s = s - so[KW * PS + x + 1] * q[x + 1];
+		s = s - so[KS * PS + x] * q[x - sj];
+		s = s - so[KS * PS + x + sj] * q[x + sj];
+		if (NINE) {
+			s = s - so[KSW * PS + x] * q[x - 1 - sj];
+			s = s - so[KNW * PS + x + 1] * q[x + 1 - sj];
+			s = s - so[KNW * PS + x + sj] * q[x - 1 + sj];
+			s = s - so[KSW * PS + x + 1 + sj] * q[x + 1 + sj];
+		}
+		res[x] = s;
+		return;
+	}
 	real_t s = qf[x];
 	s = s + so[KW * PS + x] * q[x - 1];
 	s = s + so[KW * PS + x + 1] * q[x + 1];
@@ -35,6 +53,16 @@ __global__ __launch_bounds__(256) void residual2_kernel(const real_t *__restrict
 	}
 	s = s - so[KO * PS + x] * q[x];
 	res[x] = s;
+}
+
+void matvec2(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int nstncl, hipStream_t st)
+{
+	if (II < 3 || JJ < 3) return;
+	dim3 grid((II - 2 + 255) / 256, JJ - 2);
+	if (nstncl == 5)
+		hipLaunchKernelGGL((residual2_kernel<true, true>), grid, dim3(256), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ);
+	else
+		hipLaunchKernelGGL((residual2_kernel<false, true>), grid, dim3(256), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ);
 }
 
 void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st);
@@ -54,7 +82,8 @@ void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
 		hipLaunchKernelGGL(residual2_kernel<false>, grid, dim3(256), 0, st, so, qf, q, res, II, JJ);
 }
 
-template <bool XXVII>
+// MV: qf = A q of BMG3_SymStd_UTILS_matvec (src/3d/ftn/mpi/BMG3_SymStd_UTILS_matvec.f90:80-127)
+template <bool XXVII, bool MV = false>
 __global__ __launch_bounds__(256) void residual3_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                          const real_t *__restrict__ q, real_t *__restrict__ res,
                                                          int II, int JJ, int KK, unsigned nrows)
@@ -66,6 +95,46 @@ __global__ __launch_bounds__(256) void residual3_kernel(const real_t *__restrict
 	const size_t sj = II, sk = (size_t)II * JJ, PS = sk * KK;
 	for (int i = threadIdx.x + 1; i <= II - 2; i += blockDim.x) {
 		const size_t x = (size_t)i + sj * (size_t)j + sk * (size_t)k;
+		if (MV) {
+			real_t s = so[KP * PS + x] * q[x];
+			if (XXVII) {
+				s = s - so[KPW * PS + x] * q[x - 1];
+				s = s - so[KPNW * PS + x + sj] * q[x - 1 + sj];
+				s = s - so[KPS * PS + x + sj] * q[x + sj];
+				s = s - so[KPSW * PS + x + 1 + sj] * q[x + 1 + sj];
+				s = s - so[KPW * PS + x + 1] * q[x + 1];
+				s = s - so[KPNW * PS + x + 1] * q[x + 1 - sj];
+				s = s - so[KPS * PS + x] * q[x - sj];
+				s = s - so[KPSW * PS + x] * q[x - 1 - sj];
+				s = s - so[KB * PS + x] * q[x - sk];
+				s = s - so[KBW * PS + x] * q[x - 1 - sk];
+				s = s - so[KBNW * PS + x + sj] * q[x - 1 + sj - sk];
+				s = s - so[KBN * PS + x + sj] * q[x + sj - sk];
+				s = s - so[KBNE * PS + x + 1 + sj] * q[x + 1 + sj - sk];
+				s = s - so[KBE * PS + x + 1] * q[x + 1 - sk];
+				s = s - so[KBSE * PS + x + 1] * q[x + 1 - sj - sk];
+				s = s - so[KBS * PS + x] * q[x - sj - sk];
+				s = s - so[KBSW * PS + x] * q[x - 1 - sj - sk];
+				s = s - so[KB * PS + x + sk] * q[x + sk];
+				s = s - so[KBE * PS + x + sk] * q[x - 1 + sk];
+				s = s - so[KBSE * PS + x + sj + sk] * q[x - 1 + sj + sk];
+				s = s - so[KBS * PS + x + sj + sk] * q[x + sj + sk];
+				s = s - so[KBSW * PS + x + 1 + sj + sk] * q[x + 1 + sj + sk];
+				s = s - so[KBW * PS + x + 1 + sk] * q[x + 1 + sk];
+				s = s - so[KBNW * PS + x + 1 + sk] * q[x + 1 - sj + sk];
+				s = s - so[KBN * PS + x + sk] * q[x - sj + sk];
+				s = s - so[KBNE * PS + x + sk] * q[x - 1 - sj + sk];
+			} else {
+				s = s - so[KPW * PS + x] * q[x - 1];
+				s = s - so[KPS * PS + x + sj] * q[x + sj];
+				s = s - so[KPW * PS + x + 1] * q[x + 1];
+				s = s - so[KPS * PS + x] * q[x - sj];
+				s = s - so[KB * PS + x] * q[x - sk];
+				s = s - so[KB * PS + x + sk] * q[x + sk];
+			}
+			res[x] = s;
+			continue;
+		}
 		real_t s = qf[x];
 		if (XXVII) {
 			s = s + so[KPW * PS + x] * q[x - 1];
@@ -123,6 +192,17 @@ void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
 		hipLaunchKernelGGL(residual3_kernel<true>, dim3(xcd_grid(nrows)), dim3(bs), 0, st, so, qf, q, res, II, JJ, KK, nrows);
 	else
 		hipLaunchKernelGGL(residual3_kernel<false>, dim3(xcd_grid(nrows)), dim3(bs), 0, st, so, qf, q, res, II, JJ, KK, nrows);
+}
+
+void matvec3(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int KK, int nstncl, hipStream_t st)
+{
+	if (II < 3 || JJ < 3 || KK < 3) return;
+	unsigned nrows = (unsigned)(JJ - 2) * (unsigned)(KK - 2);
+	int bs = II - 2 >= 256 ? 256 : (II - 2 > 64 ? 128 : 64);
+	if (nstncl == 14)
+		hipLaunchKernelGGL((residual3_kernel<true, true>), dim3(xcd_grid(nrows)), dim3(bs), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ, KK, nrows);
+	else
+		hipLaunchKernelGGL((residual3_kernel<false, true>), dim3(xcd_grid(nrows)), dim3(bs), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ, KK, nrows);
 }
 
 // ---------------------------------------------------------------- sum of squares

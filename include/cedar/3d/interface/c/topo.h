@@ -1,0 +1,6 @@
+/* Forwarding header: the reference spreads its C interface over several headers
+ * (include/cedar/3d/interface/c/topo.h among them); here every declaration lives in <cedar/capi.h>. */
+#ifndef CEDAR_AMD_FWD_3D_INTERFACE_C_TOPO_H
+#define CEDAR_AMD_FWD_3D_INTERFACE_C_TOPO_H
+#include <cedar/capi.h>
+#endif

@@ -124,6 +124,12 @@ void *cedar_amd_get_stream(void);
 /* ||v||_2 over the interior (grid_func::lp_norm<2>); v host or device; KK = 1 for 2D */
 double cedar_amd_l2norm(const real_t *v, len_t II, len_t JJ, len_t KK);
 
+/* qf = A q on the interior (kernels::matvec; arithmetic of src/2d/ftn/mpi/BMG2_SymStd_UTILS_matvec.f90:84-118
+ * and src/3d/ftn/mpi/BMG3_SymStd_UTILS_matvec.f90:80-127, on the serial array layout of this header:
+ * SO(II,JJ[,KK],nstncl)); nstncl = 3|5 (2D), 4|14 (3D); host or device pointers. */
+void cedar_amd_matvec2(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, int nstncl);
+void cedar_amd_matvec3(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, len_t KK, int nstncl);
+
 /* device-side gallery (src/2d/gallery.cc, src/3d/gallery.cc); `so`/`b` device or host.
  * which: 0 poisson2, 1 diag_diffusion2(dx,dy), 2 fe2, 10 poisson3, 11 diag_diffusion3, 12 fe3;
  * b (may be NULL) receives the examples' rhs (examples/basic-2d-ser/poisson.cc:15-37). */

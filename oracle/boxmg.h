@@ -59,6 +59,8 @@ void orc2_relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const rea
                         real_t *b, len_t II, len_t JJ, int ifd, int updown);
 void orc2_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                    len_t II, len_t JJ, int ifd);
+void orc2_matvec(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, int ifd);
+void orc3_matvec(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, len_t KK, int ifd);
 void orc2_restrict(const real_t *q, real_t *qc, const real_t *ci,
                    len_t II, len_t JJ, len_t IIC, len_t JJC);
 void orc2_interp_add(real_t *q, const real_t *qc, real_t *res, const real_t *so,

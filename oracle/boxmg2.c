@@ -201,6 +201,36 @@ void orc2_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *
 				                    - SO(i, j, KO) * Q(i, j);
 		}
 }
+
+/* qf = A q: src/2d/ftn/mpi/BMG2_SymStd_UTILS_matvec.f90:84-118, on the serial array layout
+ * (the MPI flavour's SO carries one more ghost; the arithmetic per point is the same).
+ * Parity: the MPI Fortran is not part of oracle/_ref (needs mpif.h/MSG); pinned through the
+ * identity matvec(q) + residual(0, q) = 0 with the _ref-pinned residual and against a dense
+ * assembly of the operator (tests/test_bmg_capi.py). */
+void orc2_matvec(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, int ifd)
+{
+#define QO(i, j) F2(qf, II, i, j)
+	for (len_t j = 2; j <= JJ - 1; j++)
+		for (len_t i = 2; i <= II - 1; i++) {
+			if (ifd != 1)
+				QO(i, j) = SO(i, j, KO) * Q(i, j)
+				           - SO(i, j, KW) * Q(i - 1, j)
+				           - SO(i + 1, j, KW) * Q(i + 1, j)
+				           - SO(i, j, KS) * Q(i, j - 1)
+				           - SO(i, j + 1, KS) * Q(i, j + 1)
+				           - SO(i, j, KSW) * Q(i - 1, j - 1)
+				           - SO(i + 1, j, KNW) * Q(i + 1, j - 1)
+				           - SO(i, j + 1, KNW) * Q(i - 1, j + 1)
+				           - SO(i + 1, j + 1, KSW) * Q(i + 1, j + 1);
+			else
+				QO(i, j) = SO(i, j, KO) * Q(i, j)
+				           - SO(i, j, KW) * Q(i - 1, j)
+				           - SO(i + 1, j, KW) * Q(i + 1, j)
+				           - SO(i, j, KS) * Q(i, j - 1)
+				           - SO(i, j + 1, KS) * Q(i, j + 1);
+		}
+#undef QO
+}
 #undef Q
 #undef QF
 #undef SO

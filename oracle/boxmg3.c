@@ -138,6 +138,52 @@ void orc3_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *
 					F3(res, II, JJ, i, j, k) = OFFDIAG7(i, j, k) - SO(i, j, k, KP) * Q(i, j, k);
 			}
 }
+
+/* qf = A q: src/3d/ftn/mpi/BMG3_SymStd_UTILS_matvec.f90:80-127 on the serial layout (see orc2_matvec) */
+void orc3_matvec(const real_t *so, const real_t *q, real_t *qf, len_t II, len_t JJ, len_t KK, int ifd)
+{
+	for (len_t k = 2; k <= KK - 1; k++)
+		for (len_t j = 2; j <= JJ - 1; j++)
+			for (len_t i = 2; i <= II - 1; i++) {
+				real_t s = SO(i, j, k, KP) * Q(i, j, k);
+				if (ifd != 1) {
+					s = s - SO(i, j, k, KPW) * Q(i - 1, j, k);
+					s = s - SO(i, j + 1, k, KPNW) * Q(i - 1, j + 1, k);
+					s = s - SO(i, j + 1, k, KPS) * Q(i, j + 1, k);
+					s = s - SO(i + 1, j + 1, k, KPSW) * Q(i + 1, j + 1, k);
+					s = s - SO(i + 1, j, k, KPW) * Q(i + 1, j, k);
+					s = s - SO(i + 1, j, k, KPNW) * Q(i + 1, j - 1, k);
+					s = s - SO(i, j, k, KPS) * Q(i, j - 1, k);
+					s = s - SO(i, j, k, KPSW) * Q(i - 1, j - 1, k);
+					s = s - SO(i, j, k, KB) * Q(i, j, k - 1);
+					s = s - SO(i, j, k, KBW) * Q(i - 1, j, k - 1);
+					s = s - SO(i, j + 1, k, KBNW) * Q(i - 1, j + 1, k - 1);
+					s = s - SO(i, j + 1, k, KBN) * Q(i, j + 1, k - 1);
+					s = s - SO(i + 1, j + 1, k, KBNE) * Q(i + 1, j + 1, k - 1);
+					s = s - SO(i + 1, j, k, KBE) * Q(i + 1, j, k - 1);
+					s = s - SO(i + 1, j, k, KBSE) * Q(i + 1, j - 1, k - 1);
+					s = s - SO(i, j, k, KBS) * Q(i, j - 1, k - 1);
+					s = s - SO(i, j, k, KBSW) * Q(i - 1, j - 1, k - 1);
+					s = s - SO(i, j, k + 1, KB) * Q(i, j, k + 1);
+					s = s - SO(i, j, k + 1, KBE) * Q(i - 1, j, k + 1);
+					s = s - SO(i, j + 1, k + 1, KBSE) * Q(i - 1, j + 1, k + 1);
+					s = s - SO(i, j + 1, k + 1, KBS) * Q(i, j + 1, k + 1);
+					s = s - SO(i + 1, j + 1, k + 1, KBSW) * Q(i + 1, j + 1, k + 1);
+					s = s - SO(i + 1, j, k + 1, KBW) * Q(i + 1, j, k + 1);
+					s = s - SO(i + 1, j, k + 1, KBNW) * Q(i + 1, j - 1, k + 1);
+					s = s - SO(i, j, k + 1, KBN) * Q(i, j - 1, k + 1);
+					s = s - SO(i, j, k + 1, KBNE) * Q(i - 1, j - 1, k + 1);
+				} else {
+					s = s - SO(i, j, k, KPW) * Q(i - 1, j, k);
+					s = s - SO(i, j + 1, k, KPS) * Q(i, j + 1, k);
+					s = s - SO(i + 1, j, k, KPW) * Q(i + 1, j, k);
+					s = s - SO(i, j, k, KPS) * Q(i, j - 1, k);
+					s = s - SO(i, j, k, KB) * Q(i, j, k - 1);
+					s = s - SO(i, j, k + 1, KB) * Q(i, j, k + 1);
+				}
+				F3(qf, II, JJ, i, j, k) = s;
+			}
+}
 #undef Q
 #undef QF
 #undef SO

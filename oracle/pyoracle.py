@@ -71,6 +71,14 @@ class Oracle:
         nst, JJ, II = so.shape
         self.L.orc2_residual(_p(so), _p(qf), _p(q), _p(res), u(II), u(JJ), int(nst == 3))
 
+    def matvec2(self, so, q, qf):
+        nst, JJ, II = so.shape
+        self.L.orc2_matvec(_p(so), _p(q), _p(qf), u(II), u(JJ), int(nst == 3))
+
+    def matvec3(self, so, q, qf):
+        nst, KK, JJ, II = so.shape
+        self.L.orc3_matvec(_p(so), _p(q), _p(qf), u(II), u(JJ), u(KK), int(nst == 4))
+
     def restrict2(self, q, qc, ci):
         JJ, II = q.shape
         JJC, IIC = qc.shape
