@@ -178,37 +178,47 @@ __device__ __forceinline__ void ldpair_so(const real_t *__restrict__ p, bool two
 
 // all operands of the pair (ie, io) of one row: 26 coefficients per point, qf, and the 3x3 q rows
 // (offsets ie-1 .. io+1); 16-byte loads, `two` = element io+1 is still inside the row
-template <bool NT>
+// NTP: the same for the three slots whose rows two row tasks of one plane share (kps, kpsw, kpnw);
+// the plane-fused pass keeps those cacheable so that the second task finds them in L2
+template <bool NT, bool NTP = NT>
 __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                             const real_t *__restrict__ q, size_t row, size_t sj, size_t sk, size_t PS,
                                             int ie, int io, bool two, C27 &ce, C27 &co,
                                             real_t (&qe)[3][3][3], real_t (&qo)[3][3][3], real_t &qfe, real_t &qfo)
 {
 	// ---- [i]-pattern streams: (value at ie, value at io)
-#define LD_I(slot, off, fe, fo)                                                        \
+#define LD_I_(N, slot, off, fe, fo)                                                    \
 {                                                                                  \
 	real_t a_, b_;                                                                 \
-	ldpair_so<NT>(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);        \
+	ldpair_so<N>(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);         \
 	ce.fe = a_; co.fo = b_;                                                        \
 }
-	LD_I(KPW, 0, pw, pw) LD_I(KPS, 0, ps, ps) LD_I(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
+#define LD_I(slot, off, fe, fo) LD_I_(NT, slot, off, fe, fo)
+#define LD_IS(slot, off, fe, fo) LD_I_(NTP, slot, off, fe, fo)
+	LD_I(KPW, 0, pw, pw) LD_IS(KPS, 0, ps, ps) LD_IS(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
 	LD_I(KBW, 0, bw, bw) LD_I(KBS, 0, bs, bs) LD_I(KBSW, 0, bsw, bsw)
-	LD_I(KPNW, sj, pnw_n, pnw_n) LD_I(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
+	LD_IS(KPNW, sj, pnw_n, pnw_n) LD_IS(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
 	LD_I(KB, sk, b_t, b_t) LD_I(KBE, sk, be_t, be_t) LD_I(KBN, sk, bn_t, bn_t) LD_I(KBNE, sk, bne_t, bne_t)
 	LD_I(KBSE, sj + sk, bse_nt, bse_nt) LD_I(KBS, sj + sk, bs_nt, bs_nt)
 #undef LD_I
+#undef LD_IS
+#undef LD_I_
 	// ---- [i+1]-pattern streams: (value at ie+1 = io, value at io+1)
-#define LD_IP(slot, off, f)                                                            \
+#define LD_IP_(N, slot, off, f)                                                        \
 {                                                                                  \
 	real_t a_, b_;                                                                 \
-	ldpair_so<NT>(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);         \
+	ldpair_so<N>(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);          \
 	ce.f = a_; co.f = b_;                                                          \
 }
-	LD_IP(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
-	LD_IP(KPW, 0, pw_e) LD_IP(KPNW, 0, pnw_e) LD_IP(KBE, 0, be_e) LD_IP(KBSE, 0, bse_e)
+#define LD_IP(slot, off, f) LD_IP_(NT, slot, off, f)
+#define LD_IPS(slot, off, f) LD_IP_(NTP, slot, off, f)
+	LD_IPS(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
+	LD_IP(KPW, 0, pw_e) LD_IPS(KPNW, 0, pnw_e) LD_IP(KBE, 0, be_e) LD_IP(KBSE, 0, bse_e)
 	LD_IP(KBSW, sj + sk, bsw_net)
 	LD_IP(KBW, sk, bw_et) LD_IP(KBNW, sk, bnw_et)
 #undef LD_IP
+#undef LD_IPS
+#undef LD_IP_
 	{
 		real_t a_, b_;
 		ldpair(qf + row + ie, true, a_, b_); qfe = a_; qfo = b_;
@@ -227,24 +237,16 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 		}
 }
 
-// fast path: one workgroup = one grid row, both i-colours.
+// one row task: lane p relaxes the pair (ie, io) = (2p+1, 2p+2) of the row at offset `row`, both
+// i-colours, in place.  xch: BS+2 doubles of LDS for the first colour's fresh values.  Every wave of
+// the workgroup must call it (one __syncthreads inside).
 //   EFIRST = true : colour with even 1-based i (i = 2,4,..) first  (UP order)
 //   EFIRST = false: odd i first                                     (DOWN order)
-template <int BS, bool EFIRST, bool NT>
-__global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                    real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                    int II, int JJ, int KK, int jb, int kb, int nrj, int nrk, TileShape ts,
-                                                    int kr0)
+template <int BS, bool EFIRST, bool NT, bool NTP = NT>
+__device__ __forceinline__ void relax27_row_task(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                 real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                 int II, size_t sj, size_t sk, size_t PS, size_t row, real_t *xch)
 {
-	__shared__ real_t xch[BS + 2];
-	const unsigned nblk = tile_blocks((unsigned)nrj, (unsigned)nrk, ts);
-	const unsigned L = xcd_remap(blockIdx.x, nblk);
-	unsigned jr, kr;
-	if (L >= nblk || !tile_rows(L, (unsigned)nrj, (unsigned)nrk, ts, jr, kr)) return; // whole workgroup leaves together
-	const size_t j = (size_t)(1 + jb + 2 * (int)jr), k = (size_t)(1 + kb + 2 * ((int)kr + kr0)); // 0-based incl. ghost
-	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
-	const size_t row = j * sj + k * sk;
-
 	const int p = threadIdx.x;
 	const int ie = 2 * p + 1, io = 2 * p + 2;     // 0-based offsets of the pair in the row
 	const bool e_ok = ie <= II - 2;                // interior?
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 	real_t qfe = 0, qfo = 0, sre = 0, sro = 0;
 
 	if (e_ok) {
-		load_pair27<NT>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		load_pair27<NT, NTP>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
 		real_t a_, b_;
 		ldpair(sor + PS + row + ie, true, a_, b_); sre = a_; sro = b_;
 	}
@@ -291,6 +293,77 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 			*reinterpret_cast<d2u *>(q + row + ie) = v;
 		} else {
 			q[row + ie] = e_new;
+		}
+	}
+}
+
+// fast path: one workgroup = one grid row, both i-colours.  Rows j = j0 + jstep*jr, jr < nrj, of the
+// planes k = 1 + kb + 2*(kr + kr0), kr < nrk.
+template <int BS, bool EFIRST, bool NT>
+__global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                    real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                    int II, int JJ, int KK, int j0, int jstep, int kb, int nrj, int nrk,
+                                                    TileShape ts, int kr0)
+{
+	__shared__ real_t xch[BS + 2];
+	const unsigned nblk = tile_blocks((unsigned)nrj, (unsigned)nrk, ts);
+	const unsigned L = xcd_remap(blockIdx.x, nblk);
+	unsigned jr, kr;
+	if (L >= nblk || !tile_rows(L, (unsigned)nrj, (unsigned)nrk, ts, jr, kr)) return; // whole workgroup leaves together
+	const size_t j = (size_t)(j0 + jstep * (int)jr), k = (size_t)(1 + kb + 2 * ((int)kr + kr0)); // 0-based incl. ghost
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
+	relax27_row_task<BS, EFIRST, NT>(so, qf, q, sor, II, sj, sk, PS, j * sj + k * sk, xch);
+}
+
+// Plane-fused pass: both row classes of the planes of one k-parity in ONE launch.  In a plane the
+// sweep relaxes the rows of class F (j-parity jbF) before those of class S; an S row reads the fresh
+// values of its two F neighbours j-1, j+1 and nothing else of this plane class changes under it.  A
+// workgroup owns a run of consecutive F rows [f0, f1) of one plane and walks it in the order
+//   F(f0), F(f0+1), S between them, F(f0+2), S, ...
+// so that the operator rows both classes need (kps, kpsw, kpnw of the plane: 3 of the 25 slot-rows a
+// row task reads) and the nine q rows are re-used from L2 a few microseconds after their first use
+// instead of being streamed again by a second launch.  The S row between two runs has its F
+// neighbours in different workgroups: it is left to a small second launch (relax27_rows over those
+// rows, j0 = first such row, jstep = 2*frun).  Same arithmetic per point, same values read =>
+// results identical to the four-launch order.
+template <int BS, bool EFIRST, bool NT>
+__global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                     real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                     int II, int JJ, int KK, int jbF, int kb, int nrk, int frun, int nrun)
+{
+	__shared__ real_t xch[2][BS + 2];
+	const unsigned nblk = (unsigned)nrk * (unsigned)nrun;
+	const unsigned L = xcd_remap(blockIdx.x, nblk);
+	if (L >= nblk) return;
+	const int kr = (int)(L / (unsigned)nrun), run = (int)(L % (unsigned)nrun);
+	const int nF = (JJ - 2 - jbF + 1) / 2, nS = (JJ - 2 - (1 - jbF) + 1) / 2;
+	const int f0 = run * frun, f1 = min(nF, f0 + frun);
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
+	const size_t plane = (size_t)(1 + kb + 2 * kr) * sk;
+	int t = 0;
+	for (int f = f0; f < f1; f++) {
+		// F row f: j = 1 + jbF + 2 f
+		relax27_row_task<BS, EFIRST, NT, false>(so, qf, q, sor, II, sj, sk, PS, plane + (size_t)(1 + jbF + 2 * f) * sj, xch[t & 1]);
+		t++;
+		// the S row both of whose F neighbours are now done (a missing neighbour = ghost row):
+		//   jbF = 0: S row g (j = 2+2g) lies between F rows g, g+1  -> after F(f): g = f-1 (f > f0)
+		//   jbF = 1: S row g (j = 1+2g) lies between F rows g-1, g  -> after F(f): g = f   (f > f0, or f = 0)
+		const int g = jbF ? f : f - 1;
+		const bool have = jbF ? (f > f0 || f == 0) : (f > f0);
+		if (have && g >= 0 && g < nS) {
+			__syncthreads(); // F stores of every wave visible before the S loads
+			relax27_row_task<BS, EFIRST, NT, false>(so, qf, q, sor, II, sj, sk, PS, plane + (size_t)(2 - jbF + 2 * g) * sj, xch[t & 1]);
+			t++;
+		}
+	}
+	// the S row beyond the last F row of the plane (its other neighbour is the ghost row)
+	if (f1 == nF && f1 > f0) {
+		const int g = jbF ? nF : nF - 1;
+		if (g < nS) {
+			// jbF = 0: g = nF-1 was not reached in the loop (needs F(nF) which does not exist)
+			// jbF = 1: g = nF    likewise
+			__syncthreads();
+			relax27_row_task<BS, EFIRST, NT, false>(so, qf, q, sor, II, sj, sk, PS, plane + (size_t)(2 - jbF + 2 * g) * sj, xch[t & 1]);
 		}
 	}
 }
@@ -371,25 +444,62 @@ static inline unsigned cap_grid(size_t n, unsigned bs)
 	return (unsigned)g;
 }
 
-// rows kr0 .. kr0+nrk_slab-1 (in units of rows of this k-parity) of the row class; nrk_slab < 0: all
+// rows j = j0 + jstep*jr (jr < nrj) of the planes kr0 .. kr0+nrk-1 (in units of planes of parity kb)
 template <int BS>
-static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                        int II, int JJ, int KK, int jb, int kb, hipStream_t st, int kr0 = 0, int nrk_slab = -1)
+static void launch_rows_at(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                           int II, int JJ, int KK, int j0, int jstep, int nrj, int kb, int nrk, hipStream_t st, int kr0 = 0)
 {
-	int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
-	if (nrk_slab >= 0) { nrk = nrk - kr0 < nrk_slab ? nrk - kr0 : nrk_slab; }
 	if (nrj <= 0 || nrk <= 0) return;
 	const TileShape ts = tile_shape_relax();
 	unsigned grid = xcd_grid(tile_blocks((unsigned)nrj, (unsigned)nrk, ts));
 	// non-temporal operator loads: measured -1.8 % per launch at 512^3 (profiles/r01_experiment_nt_loads.log)
 	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
 	if (efirst) {
-		if (nt) hipLaunchKernelGGL((relax27_rows<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
-		else hipLaunchKernelGGL((relax27_rows<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+		if (nt) hipLaunchKernelGGL((relax27_rows<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
+		else hipLaunchKernelGGL((relax27_rows<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
 	} else {
-		if (nt) hipLaunchKernelGGL((relax27_rows<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
-		else hipLaunchKernelGGL((relax27_rows<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jb, kb, nrj, nrk, ts, kr0);
+		if (nt) hipLaunchKernelGGL((relax27_rows<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
+		else hipLaunchKernelGGL((relax27_rows<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
 	}
+}
+
+// the rows of class (jb,kb)
+template <int BS>
+static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                        int II, int JJ, int KK, int jb, int kb, hipStream_t st)
+{
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, (JJ - 2 - jb + 1) / 2, kb, (KK - 2 - kb + 1) / 2, st);
+}
+
+// plane-fused pass over the planes of parity kb: F rows (parity jbF) and the S rows between them in
+// one launch, the S rows between two workgroups' runs in a second small one (see relax27_plane)
+template <int BS>
+static void launch_plane(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                         int II, int JJ, int KK, int jbF, int kb, int frun, hipStream_t st)
+{
+	const int nF = (JJ - 2 - jbF + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	if (nrk <= 0) return;
+	const int nrun = (nF + frun - 1) / frun;
+	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
+	const unsigned grid = xcd_grid((unsigned)nrk * (unsigned)nrun);
+	if (efirst) {
+		if (nt) hipLaunchKernelGGL((relax27_plane<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
+		else hipLaunchKernelGGL((relax27_plane<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
+	} else {
+		if (nt) hipLaunchKernelGGL((relax27_plane<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
+		else hipLaunchKernelGGL((relax27_plane<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
+	}
+	// S rows between runs: jbF = 0: j = 2 frun (r+1); jbF = 1: j = 1 + 2 frun (r+1), r = 0 .. nrun-2
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st);
+}
+
+// F rows per workgroup of the plane-fused pass; 0 = four launches per sweep (one per row class)
+static int plane_frun(int JJ)
+{
+	const char *e = getenv("CEDAR_AMD_FRUN"); // read per call: the tests switch it between cases
+	const int frun = e ? atoi(e) : 64;
+	if (frun <= 0 || JJ - 2 < 4 * frun) return 0; // small levels: too few runs to fill the chip
+	return frun;
 }
 
 // one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs
@@ -449,7 +559,17 @@ void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 	if (nstncl == 14) {
 		const bool up = (updown == BMG_UP);
 		const int npairs = (II - 2 + 1) / 2;
-		if (npairs <= 512) {
+		const int frun = plane_frun(JJ);
+		if (npairs <= 512 && frun > 0) {
+			// plane-fused: UP planes of parity 0 then 1, in a plane j-parity 0 rows first; DOWN the reverse
+			for (int c = 0; c < 2; c++) {
+				const int kb = up ? c : 1 - c, jbF = up ? 0 : 1;
+				if (npairs <= 64) launch_plane<64>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
+				else if (npairs <= 128) launch_plane<128>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
+				else if (npairs <= 256) launch_plane<256>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
+				else launch_plane<512>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
+			}
+		} else if (npairs <= 512) {
 			// colour pairs in sweep order: UP (j,k) parities 00,10,01,11 with even-i first
 			for (int c = 0; c < 4; c++) {
 				int cc = up ? c : 3 - c;

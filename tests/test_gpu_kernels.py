@@ -85,6 +85,26 @@ def test_kernels_3d_vs_oracle(K, oracle, case):
         check(f"{case[0]}/{k}", got[k], want[k])
 
 
+@pytest.mark.parametrize("frun", [1, 2, 3, 4, 0])
+@pytest.mark.parametrize("shape", [(20, 16, 5), (9, 17, 4), (70, 18, 6), (130, 19, 3), (11, 33, 7)], ids=str)
+def test_plane_fused_relax_matches_four_pass_order(K, oracle, monkeypatch, shape, frun):
+    """the plane-fused 27-point pass (relax27_plane + the deferred rows between runs) for every run
+    length, odd and even ny/nz, both sweep directions: bit-identical to the reference order"""
+    import problems as pb
+    monkeypatch.setenv("CEDAR_AMD_FRUN", str(frun))
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    so = pb.random_op(g, 14, 41, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 42, -1, 1), pb.uniform(g, 43, -1, 1)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip3(so, sor)
+    for ud in (0, 1):
+        want, got = q0.copy(), q0.copy()
+        oracle.relax3(so, qf, want, sor, ud)
+        K.relax3(so, qf, got, sor, ud)
+        assert np.array_equal(got, want), (shape, frun, ud, np.max(np.abs(got - want)))
+
+
 def test_device_pointers_are_used_in_place(K):
     """the same entry points accept HBM pointers (no staging): results identical"""
     from cedar_amd import capi
