@@ -493,13 +493,22 @@ static void launch_plane(bool efirst, const real_t *so, const real_t *qf, real_t
 	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st);
 }
 
-// F rows per workgroup of the plane-fused pass; 0 = four launches per sweep (one per row class)
+// F rows per workgroup of the plane-fused pass; 0 = four launches per sweep (one per row class).
+// Measured on MI355X (profiles/r01_experiment_plane_fused_relax.log): 512^3 -3..-7.5 % for runs of
+// 16..64 rows, 384^3 -11 % at 16, 256^3 and below +3..+11 % (the whole level sits closer to the
+// Infinity Cache and the four-launch order already re-reads from it) => fused only on big levels.
+// CEDAR_AMD_FRUN overrides (0 = never; n = runs of n rows wherever a plane has >= 4 runs).
 static int plane_frun(int JJ)
 {
 	const char *e = getenv("CEDAR_AMD_FRUN"); // read per call: the tests switch it between cases
-	const int frun = e ? atoi(e) : 64;
-	if (frun <= 0 || JJ - 2 < 4 * frun) return 0; // small levels: too few runs to fill the chip
-	return frun;
+	const int ny = JJ - 2;
+	if (e) {
+		const int frun = atoi(e);
+		return (frun <= 0 || ny < 4 * frun) ? 0 : frun;
+	}
+	if (ny >= 448) return 32;
+	if (ny >= 320) return 16;
+	return 0;
 }
 
 // one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs

@@ -5,7 +5,7 @@ from cedar_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 so, b = capi.gallery("fe3", (n, n, n))
 x = capi.DeviceArray(b.shape)
-for frun in [0, 256, 128, 64, 32, 16, 8, 0]:
+for frun in ([0, 256, 128, 64, 32, 16, 8, 0] if n >= 512 else [0, 64, 32, 16, 8, 4, 0]):
     os.environ["CEDAR_AMD_FRUN"] = str(frun)
     os.environ["CEDAR_AMD_NO_GRAPH"] = "1"
     s = capi.Solver(so, share_operator=True)
