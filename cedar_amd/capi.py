@@ -158,6 +158,14 @@ class Kernels:
         lib.BMG2_SymStd_residual(i(0), _p(so), _p(qf), _p(q), _p(res), C.byref(u(II)), C.byref(u(JJ)),
                                  i(0), i(int(nst == 3)), i(nst), i(0), i(0), i(0), i(0))
 
+    def matvec2(self, so, q, qf):
+        nst, JJ, II = so.shape
+        lib.cedar_amd_matvec2(_p(so), _p(q), _p(qf), u(II), u(JJ), nst)
+
+    def matvec3(self, so, q, qf):
+        nst, KK, JJ, II = so.shape
+        lib.cedar_amd_matvec3(_p(so), _p(q), _p(qf), u(II), u(JJ), u(KK), nst)
+
     def restrict2(self, q, qc, ci):
         JJ, II = q.shape
         JJC, IIC = qc.shape
