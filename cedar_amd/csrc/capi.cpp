@@ -345,6 +345,14 @@ void cedar_amd_relax3_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t
 	relax3_pass27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, jb, kb, efirst, current_stream());
 }
 
+void cedar_amd_relax3_pass_part(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                                int jb, int kb, int efirst, int part)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_pass27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, jb, kb, efirst, current_stream(), part);
+}
+
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb)
 {

@@ -53,7 +53,7 @@ void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, 
 void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int KK, int nstncl, int updown, hipStream_t st);
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st);
+                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part = 0);
 void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                     int II, int JJ, int KK, int icol, int jb, int kb, hipStream_t st);
 void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,

@@ -511,17 +511,51 @@ static int plane_frun(int JJ)
 	return 0;
 }
 
-// one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs
-// exchange halos between row classes)
+// one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs exchange halos
+// between row classes).  part: 0 = every row of the class; 1 = the rows none of whose neighbours is a
+// ghost row (2 <= j <= ny-1, 2 <= k <= nz-1 in 1-based interior numbering 1..n); 2 = the others (the
+// shell).  Rows of one class do not couple, so part 1 then part 2 equals part 0; the interior rows do
+// not read the y/z ghost layers and can run while those are still being exchanged.
+template <int BS>
+static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                        int II, int JJ, int KK, int jb, int kb, int part, hipStream_t st)
+{
+	const int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	if (nrj <= 0 || nrk <= 0) return;
+	if (part == 0) {
+		launch_rows<BS>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+		return;
+	}
+	// class rows j = 1+jb+2 jr (0-based incl. ghost): j = 1 is in the class iff jb = 0, j = ny iff it has the class parity
+	const int jlo = jb == 0 ? 1 : 0, klo = kb == 0 ? 1 : 0;
+	const int jhi = (1 + jb + 2 * (nrj - 1) == JJ - 2) ? nrj - 1 : nrj;
+	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2) ? nrk - 1 : nrk;
+	const int nji = jhi - jlo > 0 ? jhi - jlo : 0, nki = khi - klo > 0 ? khi - klo : 0;
+	if (part == 1) {
+		launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jlo, 2, nji, kb, nki, st, klo);
+		return;
+	}
+	if (nji == 0 || nki == 0) { // no interior: the shell is the whole class
+		launch_rows<BS>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+		return;
+	}
+	// shell = planes below klo / from khi (all rows), and in the planes between: rows below jlo / from jhi
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, klo, st, 0);
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, nrk - khi, st, khi);
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, jlo, kb, nki, st, klo);
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jhi, 2, nrj - jhi, kb, nki, st, klo);
+}
+
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st)
+                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part)
 {
 	const int npairs = (II - 2 + 1) / 2;
-	if (npairs <= 64) launch_rows<64>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-	else if (npairs <= 128) launch_rows<128>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-	else if (npairs <= 256) launch_rows<256>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-	else if (npairs <= 512) launch_rows<512>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+	if (npairs <= 64) launch_part<64>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
+	else if (npairs <= 128) launch_part<128>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
+	else if (npairs <= 256) launch_part<256>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
+	else if (npairs <= 512) launch_part<512>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
 	else {
+		if (part == 1) return; // rows too long for the row kernel: everything goes with the shell
 		for (int c = 0; c < 2; c++) {
 			int ib = efirst ? c : 1 - c;
 			int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;

@@ -139,11 +139,19 @@ class Halo:
             off += size
         self.total = off
         self._buf = {}
-        if self.be is not None and self.nb:
-            IntArr, OffArr = C.c_int * (6 * len(self.nb)), C.c_ulonglong * len(self.nb)
-            self._sboxes = IntArr(*[v for e in self.nb for v in e[2]])
-            self._rboxes = IntArr(*[v for e in self.nb for v in e[3]])
-            self._offs = OffArr(*[e[5] for e in self.nb])
+        # neighbour groups: "x" = across an x face/edge/corner (offset has dx != 0), "yz" = the others.
+        # The interior rows of a row pass read x ghosts but no y/z ghosts, so the "yz" group may still
+        # be in flight while they run (DistSolver3._smooth).
+        self.groups = {None: list(self.nb),
+                       "x": [e for e in self.nb if e[0][0] != 0],
+                       "yz": [e for e in self.nb if e[0][0] == 0]}
+        self._tabs = {}
+        if self.be is not None:
+            for g, nb in self.groups.items():
+                if nb:
+                    IntArr, OffArr = C.c_int * (6 * len(nb)), C.c_ulonglong * len(nb)
+                    self._tabs[g] = (IntArr(*[v for e in nb for v in e[2]]), IntArr(*[v for e in nb for v in e[3]]),
+                                     OffArr(*[e[5] for e in nb]))
         # x-face mini exchange (one box each way), see exchange_x
         nx, ny, nz = n
         self._xface = (1, 1, 1, 1, ny, nz)  # template: i0 is filled in per call
@@ -176,26 +184,30 @@ class Halo:
         i0, j0, k0, ni, nj, nk = box
         return arr[..., k0:k0 + nk, j0:j0 + nj, i0:i0 + ni]
 
-    def exchange(self, arr):
-        """fill every ghost cell that has an owner on another rank; arr: (..., KK, JJ, II)"""
-        if not self.nb:
+    def exchange(self, arr, group=None):
+        """fill every ghost cell that has an owner on another rank (group None), or only those owned
+        by the neighbours of one group ("x" / "yz"); arr: (..., KK, JJ, II).  The groups use disjoint
+        parts of the send/receive buffers, so one of each may be in flight at a time."""
+        nb = self.groups[group]
+        if not nb:
             return
         nplanes = 1
         for v in arr.shape[:-3]:
             nplanes *= int(v)
         sb, rb = self._buffers(nplanes)
         if self.be is not None:
-            self.be.box_copy(arr, nplanes, len(self.nb), self._sboxes, self._offs, sb, 0)
+            sboxes, rboxes, offs = self._tabs[group]
+            self.be.box_copy(arr, nplanes, len(nb), sboxes, offs, sb, 0)
         else:
-            for o, peer, sbox, rbox, size, off in self.nb:
+            for o, peer, sbox, rbox, size, off in nb:
                 sb[off * nplanes:(off + size) * nplanes].copy_(self._view(arr, sbox).reshape(-1))
-        sends = [(e[1], sb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in self.nb]
-        recvs = [(e[1], rb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in self.nb]
+        sends = [(e[1], sb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in nb]
+        recvs = [(e[1], rb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in nb]
         self._p2p(sends, recvs)
         if self.be is not None:
-            self.be.box_copy(arr, nplanes, len(self.nb), self._rboxes, self._offs, rb, 1)
+            self.be.box_copy(arr, nplanes, len(nb), rboxes, offs, rb, 1)
         else:
-            for o, peer, sbox, rbox, size, off in self.nb:
+            for o, peer, sbox, rbox, size, off in nb:
                 v = self._view(arr, rbox)
                 v.copy_(rb[off * nplanes:(off + size) * nplanes].reshape(v.shape))
 
@@ -248,8 +260,48 @@ class GpuBackend:
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
-    def relax_pass(self, A, b, x, sor, jb, kb, efirst):
-        self.lib.cedar_amd_relax3_pass(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), jb, kb, int(efirst))
+    def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0):
+        self.lib.cedar_amd_relax3_pass_part(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x),
+                                            jb, kb, int(efirst), part)
+
+    class _Side:
+        """`with backend.side() as h:` issues the enclosed work (library launches and collectives) on a
+        side HIP stream ordered after everything already queued on the main stream; `backend.wait(h)`
+        orders the main stream after it.  The main stream is the null stream the library and torch share;
+        torch's side streams are non-blocking, so the two really overlap."""
+
+        def __init__(self, be):
+            self.be = be
+
+        def __enter__(self):
+            be = self.be
+            if be._side is None:
+                be._side = torch.cuda.Stream(device=be.device)
+            self.main = torch.cuda.current_stream(be.device)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            be._side.wait_event(ev)
+            self.ctx = torch.cuda.stream(be._side)
+            self.ctx.__enter__()
+            self.prev = be.lib.cedar_amd_get_stream()
+            be.lib.cedar_amd_set_stream(C.c_void_p(be._side.cuda_stream))
+            return self
+
+        def __exit__(self, *exc):
+            be = self.be
+            self.done = torch.cuda.Event()
+            self.done.record(be._side)
+            be.lib.cedar_amd_set_stream(C.c_void_p(self.prev))
+            self.ctx.__exit__(*exc)
+            return False
+
+    _side = None
+
+    def side(self):
+        return GpuBackend._Side(self)
+
+    def wait(self, h):
+        torch.cuda.current_stream(self.device).wait_event(h.done)
 
     def relax_fixup(self, A, b, x, sor, icol, jb, kb):
         self.lib.cedar_amd_relax3_fixup(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), icol, jb, kb)
@@ -315,12 +367,13 @@ class DistSolver3:
     """cedar::cdr3::mpi::solver equivalent for Dirichlet problems, point relaxation, V(pre,post)."""
 
     def __init__(self, backend, topo, A_local, nrelax_pre=2, nrelax_post=1, min_coarse=3, max_iter=10, tol=1e-8,
-                 agglomerate_below=64):
+                 agglomerate_below=64, overlap_min=96):
         """A_local: (nst, nz+2, ny+2, nx+2) local part of the global operator (ghost layers are
         filled here by exchange; entries coupling to a neighbouring rank must be present)."""
         self.be, self.topo = backend, topo
         self.pre, self.post, self.max_iter, self.tol = nrelax_pre, nrelax_post, max_iter, tol
         self.min_coarse = min_coarse
+        self.overlap_min = overlap_min
         staged = dist.is_initialized() and dist.get_backend() == "gloo" and A_local.is_cuda
         nst = A_local.shape[0]
         n = tuple(int(s) - 2 for s in A_local.shape[1:][::-1])
@@ -350,6 +403,9 @@ class DistSolver3:
                     assert n[d] % 2 == 0, f"level {l}: local extent {n[d]} in dim {d} must be even"
             shp = (n[2] + 2, n[1] + 2, n[0] + 2)
             L.halo = Halo(topo, n, A_local.device, staged, backend)
+            # halo of one row pass in flight under the interior rows of the next (side stream): only
+            # where a pass is long enough to hide it and there is a y/z neighbour to talk to
+            L.overlap = bool(L.halo.groups["yz"]) and min(n) >= overlap_min and hasattr(backend, "side")
             L.res = backend.zeros(shp)
             L.sor = backend.zeros((2,) + shp)
             if l == 0:
@@ -410,6 +466,7 @@ class DistSolver3:
         be, t = self.be, self.topo
         nst = L.A.shape[0]
         nx = L.n[0]
+        pending = None  # handle of the y/z halo exchange in flight on the side stream
         for _ in range(n):
             if nst == 4:
                 for c in range(2):
@@ -420,12 +477,28 @@ class DistSolver3:
             for c in range(4):
                 cc = c if up else 3 - c
                 jb, kb = cc & 1, cc >> 1
-                be.relax_pass(L.A, b, x, L.sor, jb, kb, up)
+                if L.overlap:
+                    # interior rows first: they read no y/z ghost, whose exchange (previous pass) may
+                    # still be running on the side stream; then join and do the shell rows
+                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up, 1)
+                    if pending is not None:
+                        be.wait(pending)
+                        pending = None
+                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up, 2)
+                else:
+                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up)
                 if t.p[0] > 1:
                     # second i-colour at the x-boundary needs the neighbour's fresh first colour
                     if L.halo.exchange_x(x, to_minus=up):
                         be.relax_fixup(L.A, b, x, L.sor, nx if up else 1, jb, kb)
-                L.halo.exchange(x)
+                if L.overlap:
+                    L.halo.exchange(x, "x")  # x ghosts are read by every row of the next pass: not deferred
+                    with be.side() as pending:
+                        L.halo.exchange(x, "yz")
+                else:
+                    L.halo.exchange(x)
+        if pending is not None:
+            be.wait(pending)
 
     def _coarse_solve(self, x, b):
         """levels la.. : gather the right-hand side, one single-domain cycle (or the direct solve when

@@ -146,6 +146,11 @@ void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len
  * efirst != 0: even 1-based i first (the UP order) */
 void cedar_amd_relax3_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                            int jb, int kb, int efirst);
+/* the same restricted to a part of the class rows: part 1 = rows none of whose j,k neighbours is a
+ * ghost row (they do not read the y/z ghost layers and may run while those are being exchanged),
+ * part 2 = the remaining shell, part 0 = all.  Rows of a class do not couple: 1 then 2 equals 0. */
+void cedar_amd_relax3_pass_part(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                                int jb, int kb, int efirst, int part);
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb);

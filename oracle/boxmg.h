@@ -80,6 +80,8 @@ void orc3_relax_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *
                    len_t II, len_t JJ, len_t KK, int ifd, int updown);
 void orc3_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                        len_t II, len_t JJ, len_t KK, int ifd, int pts);
+void orc3_relax_colour_part(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                            len_t II, len_t JJ, len_t KK, int pts, int part);
 void orc3_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                        len_t II, len_t JJ, len_t KK, int i, int jb, int kb);
 void orc3_setup_interp_ex(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,

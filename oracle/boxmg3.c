@@ -115,6 +115,23 @@ void orc3_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real
 	}
 }
 
+/* one 27-pt colour restricted to a part of its rows: part 1 = rows with 3 <= j <= JJ-2 and
+ * 3 <= k <= KK-2 (no ghost row among their neighbours), part 2 = the others (the shell), 0 = all.
+ * Rows of one colour do not couple, so interior-then-shell equals the plain colour pass; the
+ * domain-decomposed driver computes the interior while the previous halo is still in flight. */
+void orc3_relax_colour_part(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                            len_t II, len_t JJ, len_t KK, int pts, int part)
+{
+	int I1 = (int)II - 1, J1 = (int)JJ - 1, K1 = (int)KK - 1;
+	for (int k = 2 + ((pts - 1) / 4) % 2; k <= K1; k += 2)
+		for (int j = 2 + ((pts - 1) / 2) % 2; j <= J1; j += 2) {
+			const int inner = j >= 3 && j <= J1 - 1 && k >= 3 && k <= K1 - 1;
+			if ((part == 1 && !inner) || (part == 2 && inner)) continue;
+			for (int i = 2 + (pts - 1) % 2; i <= I1; i += 2)
+				Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+		}
+}
+
 /* recompute the 27-pt points of 1-based column i in the rows of class (jb,kb) */
 void orc3_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                        len_t II, len_t JJ, len_t KK, int i, int jb, int kb)

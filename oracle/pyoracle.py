@@ -123,6 +123,11 @@ class Oracle:
         nst, KK, JJ, II = so.shape
         self.L.orc3_relax_colour(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), pts)
 
+    def relax_colour3_part(self, so, qf, q, sor, pts, part):
+        nst, KK, JJ, II = so.shape
+        assert nst == 14
+        self.L.orc3_relax_colour_part(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), pts, part)
+
     def relax_column3(self, so, qf, q, sor, i1, jb, kb):
         nst, KK, JJ, II = so.shape
         self.L.orc3_relax_column(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), i1, jb, kb)

@@ -21,10 +21,24 @@ class CpuBackend:
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64)
 
-    def relax_pass(self, A, b, x, sor, jb, kb, efirst):
-        # the fused device kernel = the two i-colours of the row class back to back, no exchange between
+    def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0):
+        # the fused device kernel = the two i-colours of the row class back to back, no exchange between;
+        # part 1 / 2 = interior rows / shell rows of the class (cedar_amd_relax3_pass_part)
         for ib in ((0, 1) if efirst else (1, 0)):
-            self.O.relax_colour3(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb)
+            self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, part)
+
+    class _Side:  # CPU: no streams, the "side" work simply runs in program order
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    def side(self):
+        return CpuBackend._Side()
+
+    def wait(self, h):
+        pass
 
     def relax_fixup(self, A, b, x, sor, icol, jb, kb):
         self.O.relax_column3(self._n(A), self._n(b), self._n(x), self._n(sor), icol + 1, jb, kb)

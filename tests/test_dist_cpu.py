@@ -50,7 +50,8 @@ def _worker(rank, world, port, case, outdir):
         A *= m
         b = torch.from_numpy(np.ascontiguousarray(gb[sl])) * m
         x = torch.zeros_like(b)
-        s = DistSolver3(CpuBackend(), topo, A, max_iter=6, agglomerate_below=agg)
+        # overlap_min=4: the interior-rows-first / deferred y-z halo ordering on every level that has an interior
+        s = DistSolver3(CpuBackend(), topo, A, max_iter=6, agglomerate_below=agg, overlap_min=4)
         h = s.solve(b, x)
         np.save(os.path.join(outdir, f"x{rank}.npy"), x.numpy())
         if rank == 0:
@@ -82,6 +83,7 @@ CASES = [
     ("rand27", (4, 4, 4), (2, 2, 2), 2),
     ("rand27", (8, 8, 8), (2, 2, 2), 32),
     ("rand27", (6, 8, 8), (1, 2, 2), 2),
+    ("rand27", (10, 12, 16), (1, 1, 2), 4),
 ]
 
 
