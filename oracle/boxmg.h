@@ -74,6 +74,21 @@ int orc2_setup_cg(const real_t *so, len_t II, len_t JJ, int nstncl,
 int orc2_solve_cg(real_t *q, const real_t *qf, len_t II, len_t JJ,
                   const real_t *abd, real_t *bbd, len_t nabd1, len_t nabd2);
 
+/* ---- 2D periodic branches (boxmg2_per.c; ipn = 1 per_y, 2 per_x, 3 per_xy) ---- */
+void orc2_setup_interp_per(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
+                           len_t IIC, len_t JJC, int ifd, int ipn);
+void orc2_relax_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, int ifd, int updown, int ipn);
+void orc2_restrict_per(real_t *q, real_t *qc, const real_t *ci,
+                       len_t II, len_t JJ, len_t IIC, len_t JJC, int ipn);
+void orc2_interp_add_per(real_t *q, const real_t *qc, real_t *res, const real_t *so,
+                         const real_t *ci, len_t IIC, len_t JJC, len_t IIF, len_t JJF, int ipn);
+void orc2_galerkin_per(const real_t *so, real_t *soc, const real_t *ci, len_t IIF, len_t JJF,
+                       len_t IIC, len_t JJC, int ifd, int ipn);
+int orc2_setup_cg_per(const real_t *so, len_t II, len_t JJ, int nstncl, real_t *abd, len_t nabd1, int ipn);
+int orc2_solve_cg_per(real_t *q, const real_t *qf, len_t II, len_t JJ,
+                      const real_t *abd, real_t *bbd, len_t nabd1, int ipn);
+
 /* ---- 3D kernels (boxmg3.c) ---- */
 void orc3_setup_recip(const real_t *so, real_t *sor, len_t II, len_t JJ, len_t KK);
 void orc3_relax_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
@@ -107,6 +122,8 @@ int orc_dpttrf(int n, real_t *d, real_t *e);
 void orc_dpttrs(int n, const real_t *d, const real_t *e, real_t *b);
 int orc_dpbtrf_upper(int n, int kd, real_t *ab, int ldab);
 void orc_dpbtrs_upper(int n, int kd, const real_t *ab, int ldab, real_t *b);
+int orc_dpotrf_upper(int n, real_t *a, int lda);
+void orc_dpotrs_upper(int n, const real_t *a, int lda, real_t *b);
 
 /* ---- norms (include/cedar/2d/grid_func.h:42-53, src/2d/grid_func.cc:118-134) ---- */
 real_t orc_l2_norm2(const real_t *v, len_t II, len_t JJ);

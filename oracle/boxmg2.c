@@ -316,16 +316,108 @@ static inline real_t lump(real_t off, real_t diag, real_t s, real_t ep, real_t z
 	return off + (diag - s) * rmax(diag - (1.0 + ep) * s, 0.0) / (fabs(diag - (1.0 + ep) * s) + zeps);
 }
 
+/* ---- operator-induced interpolation: the three point formulas of BMG2_SymStd_SETUP_interp_OI.f90,
+ * shared by the non-periodic (:84-256) and the periodic (:258-618) index drivers.  (i,j) = fine
+ * point the formula is centred on, (ic,jc) = coarse entry that receives the weights. */
+#define SO(i, j, s) S2(so, IIF, JJF, i, j, s)
+#define CIW(ic, jc, s) S2(ci, IIC, JJC, ic, jc, s)
+static void ci_xedge(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t IIC, len_t JJC,
+                     int ifd, int i, int j, int ic, int jc)
+{
+	const real_t zeps = DBL_EPSILON; /* EPSILON(1.D0), :70 */
+	real_t a, b, ep, sum;
+	if (ifd != 1) {
+		a = SO(i, j, KW) + SO(i, j, KNW) + SO(i, j + 1, KSW);
+		b = SO(i - 1, j, KW) + SO(i - 1, j, KSW) + SO(i - 1, j + 1, KNW);
+	} else {
+		a = SO(i, j, KW);
+		b = SO(i - 1, j, KW);
+	}
+	ep = rmin(fabs(a / SO(i - 1, j, KO)), fabs(b / SO(i - 1, j, KO)));
+	sum = a + b + SO(i - 1, j, KS) + SO(i - 1, j + 1, KS);
+	sum = lump(a + b, SO(i - 1, j, KO), sum, ep, zeps);
+	sum = 1.0 / sum;
+	CIW(ic, jc, LR) = a * sum;
+	CIW(ic, jc, LL) = b * sum;
+}
+
+static void ci_yedge(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t IIC, len_t JJC,
+                     int ifd, int i, int j, int ic, int jc)
+{
+	const real_t zeps = DBL_EPSILON;
+	real_t a, b, ep, sum;
+	if (ifd != 1) {
+		a = SO(i, j, KS) + SO(i, j, KNW) + SO(i + 1, j, KSW);
+		b = SO(i, j - 1, KS) + SO(i, j - 1, KSW) + SO(i + 1, j - 1, KNW);
+	} else {
+		a = SO(i, j, KS);
+		b = SO(i, j - 1, KS);
+	}
+	ep = rmin(fabs(a / SO(i, j - 1, KO)), fabs(b / SO(i, j - 1, KO)));
+	sum = a + b + SO(i, j - 1, KW) + SO(i + 1, j - 1, KW);
+	sum = lump(a + b, SO(i, j - 1, KO), sum, ep, zeps);
+	sum = 1.0 / sum;
+	CIW(ic, jc, LA) = a * sum;
+	CIW(ic, jc, LB) = b * sum;
+}
+
+static void ci_centre(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t IIC, len_t JJC,
+                      int ifd, int i, int j, int ic, int jc)
+{
+	const real_t zeps = DBL_EPSILON;
+	real_t ep, sum, s;
+	real_t d = SO(i - 1, j - 1, KO);
+	if (ifd != 1) {
+		sum = SO(i - 1, j - 1, KW) + SO(i - 1, j, KNW) + SO(i - 1, j, KS)
+		      + SO(i, j, KSW) + SO(i, j - 1, KW) + SO(i, j - 1, KNW)
+		      + SO(i - 1, j - 1, KS) + SO(i - 1, j - 1, KSW);
+		ep = rmin(rmin(fabs((SO(i - 1, j - 1, KSW) + SO(i - 1, j - 1, KW)
+		                     + SO(i - 1, j, KNW)) / d),
+		               fabs((SO(i - 1, j, KNW) + SO(i - 1, j, KS)
+		                     + SO(i, j, KSW)) / d)),
+		          rmin(fabs((SO(i, j, KSW) + SO(i, j - 1, KW)
+		                     + SO(i, j - 1, KNW)) / d),
+		               fabs((SO(i, j - 1, KNW) + SO(i - 1, j - 1, KS)
+		                     + SO(i - 1, j - 1, KSW)) / d)));
+		sum = lump(sum, d, sum, ep, zeps);
+		s = 1.0 / sum;
+		CIW(ic, jc, LSW) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LL)
+		                    + SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LB)
+		                    + SO(i - 1, j - 1, KSW)) * s;
+		CIW(ic, jc, LSE) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LR)
+		                    + SO(i, j - 1, KW) * CIW(ic, jc, LB)
+		                    + SO(i, j - 1, KNW)) * s;
+		CIW(ic, jc, LNW) = (SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LA)
+		                    + SO(i - 1, j, KS) * CIW(ic, jc, LL)
+		                    + SO(i - 1, j, KNW)) * s;
+		CIW(ic, jc, LNE) = (SO(i - 1, j, KS) * CIW(ic, jc, LR)
+		                    + SO(i, j - 1, KW) * CIW(ic, jc, LA)
+		                    + SO(i, j, KSW)) * s;
+	} else {
+		sum = SO(i - 1, j - 1, KW) + SO(i - 1, j, KS) + SO(i, j - 1, KW)
+		      + SO(i - 1, j - 1, KS);
+		ep = rmin(rmin(fabs(SO(i - 1, j - 1, KW) / d), fabs(SO(i - 1, j, KS) / d)),
+		          rmin(fabs(SO(i, j - 1, KW) / d), fabs(SO(i - 1, j - 1, KS) / d)));
+		sum = lump(sum, d, sum, ep, zeps);
+		s = 1.0 / sum;
+		CIW(ic, jc, LSW) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LL)
+		                    + SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LB)) * s;
+		CIW(ic, jc, LSE) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LR)
+		                    + SO(i, j - 1, KW) * CIW(ic, jc, LB)) * s;
+		CIW(ic, jc, LNW) = (SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LA)
+		                    + SO(i - 1, j, KS) * CIW(ic, jc, LL)) * s;
+		CIW(ic, jc, LNE) = (SO(i - 1, j, KS) * CIW(ic, jc, LR)
+		                    + SO(i, j - 1, KW) * CIW(ic, jc, LA)) * s;
+	}
+}
+#undef CIW
+
 /* src/2d/ftn/BMG2_SymStd_SETUP_interp_OI.f90:84-256 (non-periodic) */
 void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
                        len_t IIC, len_t JJC, int ifd)
 {
-#define SO(i, j, s) S2(so, IIF, JJF, i, j, s)
-#define CIW(ic, jc, s) S2(ci, IIC, JJC, ic, jc, s)
-	const real_t zeps = DBL_EPSILON; /* EPSILON(1.D0), :70 */
 	int IIC1 = (int)IIC - 1, JJC1 = (int)JJC - 1;
 	int IICF1 = ((int)IIF - 2) / 2 + 2, JJCF1 = ((int)JJF - 2) / 2 + 2;
-	real_t a, b, ep, sum, s;
 	int i, j;
 
 	/* x-edges: fine points between two coarse points on a coarse row (:112-130 / :196-213) */
@@ -335,19 +427,7 @@ void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
 		i = 2;
 		for (int ic = 3; ic <= IICF1; ic++) {
 			i += 2;
-			if (ifd != 1) {
-				a = SO(i, j, KW) + SO(i, j, KNW) + SO(i, j + 1, KSW);
-				b = SO(i - 1, j, KW) + SO(i - 1, j, KSW) + SO(i - 1, j + 1, KNW);
-			} else {
-				a = SO(i, j, KW);
-				b = SO(i - 1, j, KW);
-			}
-			ep = rmin(fabs(a / SO(i - 1, j, KO)), fabs(b / SO(i - 1, j, KO)));
-			sum = a + b + SO(i - 1, j, KS) + SO(i - 1, j + 1, KS);
-			sum = lump(a + b, SO(i - 1, j, KO), sum, ep, zeps);
-			sum = 1.0 / sum;
-			CIW(ic, jc, LR) = a * sum;
-			CIW(ic, jc, LL) = b * sum;
+			ci_xedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
 		}
 	}
 	/* y-edges (:131-149 / :214-231) */
@@ -357,19 +437,7 @@ void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
 		i = 0;
 		for (int ic = 2; ic <= IIC1; ic++) {
 			i += 2;
-			if (ifd != 1) {
-				a = SO(i, j, KS) + SO(i, j, KNW) + SO(i + 1, j, KSW);
-				b = SO(i, j - 1, KS) + SO(i, j - 1, KSW) + SO(i + 1, j - 1, KNW);
-			} else {
-				a = SO(i, j, KS);
-				b = SO(i, j - 1, KS);
-			}
-			ep = rmin(fabs(a / SO(i, j - 1, KO)), fabs(b / SO(i, j - 1, KO)));
-			sum = a + b + SO(i, j - 1, KW) + SO(i + 1, j - 1, KW);
-			sum = lump(a + b, SO(i, j - 1, KO), sum, ep, zeps);
-			sum = 1.0 / sum;
-			CIW(ic, jc, LA) = a * sum;
-			CIW(ic, jc, LB) = b * sum;
+			ci_yedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
 		}
 	}
 	/* cell centres (:150-188 / :232-255) */
@@ -379,52 +447,95 @@ void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
 		i = 2;
 		for (int ic = 3; ic <= IICF1; ic++) {
 			i += 2;
-			real_t d = SO(i - 1, j - 1, KO);
-			if (ifd != 1) {
-				sum = SO(i - 1, j - 1, KW) + SO(i - 1, j, KNW) + SO(i - 1, j, KS)
-				      + SO(i, j, KSW) + SO(i, j - 1, KW) + SO(i, j - 1, KNW)
-				      + SO(i - 1, j - 1, KS) + SO(i - 1, j - 1, KSW);
-				ep = rmin(rmin(fabs((SO(i - 1, j - 1, KSW) + SO(i - 1, j - 1, KW)
-				                     + SO(i - 1, j, KNW)) / d),
-				               fabs((SO(i - 1, j, KNW) + SO(i - 1, j, KS)
-				                     + SO(i, j, KSW)) / d)),
-				          rmin(fabs((SO(i, j, KSW) + SO(i, j - 1, KW)
-				                     + SO(i, j - 1, KNW)) / d),
-				               fabs((SO(i, j - 1, KNW) + SO(i - 1, j - 1, KS)
-				                     + SO(i - 1, j - 1, KSW)) / d)));
-				sum = lump(sum, d, sum, ep, zeps);
-				s = 1.0 / sum;
-				CIW(ic, jc, LSW) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LL)
-				                    + SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LB)
-				                    + SO(i - 1, j - 1, KSW)) * s;
-				CIW(ic, jc, LSE) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LR)
-				                    + SO(i, j - 1, KW) * CIW(ic, jc, LB)
-				                    + SO(i, j - 1, KNW)) * s;
-				CIW(ic, jc, LNW) = (SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LA)
-				                    + SO(i - 1, j, KS) * CIW(ic, jc, LL)
-				                    + SO(i - 1, j, KNW)) * s;
-				CIW(ic, jc, LNE) = (SO(i - 1, j, KS) * CIW(ic, jc, LR)
-				                    + SO(i, j - 1, KW) * CIW(ic, jc, LA)
-				                    + SO(i, j, KSW)) * s;
-			} else {
-				sum = SO(i - 1, j - 1, KW) + SO(i - 1, j, KS) + SO(i, j - 1, KW)
-				      + SO(i - 1, j - 1, KS);
-				ep = rmin(rmin(fabs(SO(i - 1, j - 1, KW) / d), fabs(SO(i - 1, j, KS) / d)),
-				          rmin(fabs(SO(i, j - 1, KW) / d), fabs(SO(i - 1, j - 1, KS) / d)));
-				sum = lump(sum, d, sum, ep, zeps);
-				s = 1.0 / sum;
-				CIW(ic, jc, LSW) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LL)
-				                    + SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LB)) * s;
-				CIW(ic, jc, LSE) = (SO(i - 1, j - 1, KS) * CIW(ic, jc - 1, LR)
-				                    + SO(i, j - 1, KW) * CIW(ic, jc, LB)) * s;
-				CIW(ic, jc, LNW) = (SO(i - 1, j - 1, KW) * CIW(ic - 1, jc, LA)
-				                    + SO(i - 1, j, KS) * CIW(ic, jc, LL)) * s;
-				CIW(ic, jc, LNE) = (SO(i - 1, j, KS) * CIW(ic, jc, LR)
-				                    + SO(i, j - 1, KW) * CIW(ic, jc, LA)) * s;
-			}
+			ci_centre(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
 		}
 	}
-#undef CIW
+}
+
+/* the fine index the periodic driver pairs with the next coarse index: I <- MAX(MOD(I+2,IIFC), MIN(I+2,3))
+ * (:327, :378 ...): steps by two and wraps past the last fine point onto index 3 */
+static int per_next(int i, int nfc)
+{
+	int a = (i + 2) % nfc, b = i + 2 < 3 ? i + 2 : 3;
+	return a > b ? a : b;
+}
+
+/* src/2d/ftn/BMG2_SymStd_SETUP_interp_OI.f90:258-618: periodic in x (ipn 2), y (1) or both (3) */
+void orc2_setup_interp_per(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
+                           len_t IIC, len_t JJC, int ifd, int ipn)
+{
+	const int per_x = ipn == 2 || ipn == 3, per_y = ipn == 1 || ipn == 3;
+	const int IIC1 = (int)IIC - 1, JJC1 = (int)JJC - 1;
+	const int IIF1 = (int)IIF - 1, IIF2 = (int)IIF - 2, JJF1 = (int)JJF - 1, JJF2 = (int)JJF - 2;
+	const int IICF = ((int)IIF - 2) / 2 + 3, JJCF = ((int)JJF - 2) / 2 + 3;
+	const int IICF1 = IICF - 1, JJCF1 = JJCF - 1;
+	const int IIFC = 2 * (IICF - 2) + 2, JJFC = 2 * (JJCF - 2) + 2;
+	int IBEG = 2, IBEGC = 3, IBEG_x = 2, IEND_x = IIF2, IENDC = IICF1, JENDC = JJCF1;
+	int JBEG = 2, JBEGC = 3, JBEG_y = 2, JEND_y = JJF2;
+	int i, j;
+	if (per_x) { /* :294-302 */
+		IBEG = 0; IBEGC = 2;
+		if ((int)IIC == IICF) { IENDC = IICF; IBEG_x = 3; IEND_x = IIF1; }
+	}
+	if (per_y) { /* :307-315 */
+		JBEG = 0; JBEGC = 2;
+		if ((int)JJC == JJCF) { JENDC = JJCF; JBEG_y = 3; JEND_y = JJF1; }
+	}
+	/* x-edges on the coarse rows (:322-341 / :475-492) */
+	j = 0;
+	for (int jc = 2; jc <= JJC1; jc++) {
+		j += 2;
+		i = IBEG;
+		for (int ic = IBEGC; ic <= IENDC; ic++) {
+			i = per_next(i, IIFC);
+			ci_xedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
+		}
+	}
+	if (per_y) { /* the two wrapped coarse rows (:343-375 / :495-526) */
+		i = IBEG;
+		for (int ic = IBEGC; ic <= IENDC; ic++) {
+			i = per_next(i, IIFC);
+			ci_xedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, JBEG_y, ic, (int)JJC);
+		}
+		i = IBEG;
+		for (int ic = IBEGC; ic <= IENDC; ic++) {
+			i = per_next(i, IIFC);
+			ci_xedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, JEND_y, ic, 1);
+		}
+	}
+	/* y-edges on the coarse columns (:377-394 / :529-546) */
+	j = JBEG;
+	for (int jc = JBEGC; jc <= JENDC; jc++) {
+		j = per_next(j, JJFC);
+		i = 0;
+		for (int ic = 2; ic <= IIC1; ic++) {
+			i += 2;
+			ci_yedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
+		}
+	}
+	if (per_x) { /* the two wrapped coarse columns (:396-428 / :548-579) */
+		j = JBEG;
+		for (int jc = JBEGC; jc <= JENDC; jc++) {
+			j = per_next(j, JJFC);
+			ci_yedge(so, ci, IIF, JJF, IIC, JJC, ifd, IBEG_x, j, (int)IIC, jc);
+		}
+		j = JBEG;
+		for (int jc = JBEGC; jc <= JENDC; jc++) {
+			j = per_next(j, JJFC);
+			ci_yedge(so, ci, IIF, JJF, IIC, JJC, ifd, IEND_x, j, 1, jc);
+		}
+	}
+	/* cell centres (:431-466 / :581-608) */
+	j = JBEG;
+	for (int jc = JBEGC; jc <= JENDC; jc++) {
+		j = per_next(j, JJFC);
+		i = IBEG;
+		for (int ic = IBEGC; ic <= IENDC; ic++) {
+			i = per_next(i, IIFC);
+			ci_centre(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
+		}
+	}
+	(void)IIF1; (void)JJF1;
 }
 
 /* Galerkin coarse operator A_c = P^T A P.

@@ -101,3 +101,52 @@ void orc_dpbtrs_upper(int n, int kd, const real_t *ab, int ldab, real_t *b)
 		}
 	}
 }
+
+/* ---- dense Cholesky for the periodic coarse solve (BMG2_SymStd_SETUP_cg_LU.f90:214, SOLVE_cg.f90:107)
+ * DPOTF2 / DPOTRS, UPLO = 'U', NRHS = 1, reference-BLAS operation order (dpotf2.f, dtrsm.f). */
+#define A(r, c) a[(size_t)((r)-1) + (size_t)lda * (size_t)((c)-1)]
+int orc_dpotrf_upper(int n, real_t *a, int lda)
+{
+	for (int j = 1; j <= n; j++) {
+		real_t dot = 0.0;
+		for (int i = 1; i <= j - 1; i++) dot = dot + A(i, j) * A(i, j);
+		real_t ajj = A(j, j) - dot;
+		if (ajj <= 0.0 || ajj != ajj) {
+			A(j, j) = ajj;
+			return j;
+		}
+		ajj = sqrt(ajj);
+		A(j, j) = ajj;
+		if (j < n) {
+			/* DGEMV('T', j-1, n-j, -1, A(1,j+1), lda, A(1,j), 1, 1, A(j,j+1), lda) */
+			for (int c = j + 1; c <= n; c++) {
+				real_t temp = 0.0;
+				for (int i = 1; i <= j - 1; i++) temp = temp + A(i, c) * A(i, j);
+				A(j, c) = A(j, c) + (-1.0) * temp;
+			}
+			/* DSCAL(n-j, 1/ajj, A(j,j+1), lda) */
+			real_t r = 1.0 / ajj;
+			for (int c = j + 1; c <= n; c++) A(j, c) = r * A(j, c);
+		}
+	}
+	return 0;
+}
+
+void orc_dpotrs_upper(int n, const real_t *a, int lda, real_t *b)
+{
+	/* DTRSM('L','U','T','N'): b := inv(U^T) b */
+	for (int i = 1; i <= n; i++) {
+		real_t temp = b[i - 1];
+		for (int k = 1; k <= i - 1; k++) temp = temp - A(k, i) * b[k - 1];
+		temp = temp / A(i, i);
+		b[i - 1] = temp;
+	}
+	/* DTRSM('L','U','N','N'): b := inv(U) b */
+	for (int k = n; k >= 1; k--) {
+		if (b[k - 1] != 0.0) {
+			b[k - 1] = b[k - 1] / A(k, k);
+			for (int i = 1; i <= k - 1; i++) b[i - 1] = b[i - 1] - b[k - 1] * A(i, k);
+		}
+	}
+}
+#undef A

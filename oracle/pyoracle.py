@@ -50,9 +50,12 @@ class Oracle:
         _, JJ, II = so.shape
         self.L.orc2_setup_recip(_p(so), _p(sor), u(II), u(JJ))
 
-    def relax2(self, so, qf, q, sor, updown):
+    def relax2(self, so, qf, q, sor, updown, ibc=0):
         nst, JJ, II = so.shape
-        self.L.orc2_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
+        if ibc:
+            self.L.orc2_relax_gs_per(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown, ibc)
+        else:
+            self.L.orc2_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
 
     def setup_lines2(self, so, sor, d):
         _, JJ, II = so.shape
@@ -79,36 +82,54 @@ class Oracle:
         nst, KK, JJ, II = so.shape
         self.L.orc3_matvec(_p(so), _p(q), _p(qf), u(II), u(JJ), u(KK), int(nst == 4))
 
-    def restrict2(self, q, qc, ci):
+    def restrict2(self, q, qc, ci, ibc=0):
         JJ, II = q.shape
         JJC, IIC = qc.shape
-        self.L.orc2_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(IIC), u(JJC))
+        if ibc:
+            self.L.orc2_restrict_per(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), ibc)
+        else:
+            self.L.orc2_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(IIC), u(JJC))
 
-    def interp_add2(self, q, qc, res, so, ci):
+    def interp_add2(self, q, qc, res, so, ci, ibc=0):
         JJ, II = q.shape
         JJC, IIC = qc.shape
-        self.L.orc2_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ))
+        if ibc:
+            self.L.orc2_interp_add_per(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ), ibc)
+        else:
+            self.L.orc2_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ))
 
-    def setup_interp2(self, so, ci):
+    def setup_interp2(self, so, ci, ibc=0):
         nst, JJ, II = so.shape
         _, JJC, IIC = ci.shape
-        self.L.orc2_setup_interp(_p(so), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3))
+        if ibc:
+            self.L.orc2_setup_interp_per(_p(so), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), ibc)
+        else:
+            self.L.orc2_setup_interp(_p(so), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3))
 
-    def galerkin2(self, so, soc, ci):
+    def galerkin2(self, so, soc, ci, ibc=0):
         nst, JJ, II = so.shape
         _, JJC, IIC = ci.shape
-        self.L.orc2_galerkin(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3))
+        if ibc:
+            self.L.orc2_galerkin_per(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), ibc)
+        else:
+            self.L.orc2_galerkin(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3))
 
-    def setup_cg2(self, so, abd):
+    def setup_cg2(self, so, abd, ibc=0):
+        """abd: (n, nx+2) band storage, or (n, n) dense for a periodic ibc (2d/solver.h:110-114)"""
         nst, JJ, II = so.shape
         n2, n1 = abd.shape
+        if ibc:
+            return self.L.orc2_setup_cg_per(_p(so), u(II), u(JJ), nst, _p(abd), u(n1), ibc)
         return self.L.orc2_setup_cg(_p(so), u(II), u(JJ), nst, _p(abd), u(n1), u(n2))
 
-    def solve_cg2(self, q, qf, abd):
+    def solve_cg2(self, q, qf, abd, ibc=0):
         JJ, II = q.shape
         n2, n1 = abd.shape
         bbd = np.zeros(n2)
-        self.L.orc2_solve_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2))
+        if ibc:
+            self.L.orc2_solve_cg_per(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), ibc)
+        else:
+            self.L.orc2_solve_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2))
 
     # ---------------- 3D ----------------
     def setup_recip3(self, so, sor):
@@ -246,9 +267,9 @@ class Ref:
         nst, JJ, II = so.shape
         self.L.BMG2_SymStd_SETUP_recip(_p(so), _p(sor), u(II), u(JJ), nst, 2)
 
-    def relax2(self, so, qf, q, sor, updown):
+    def relax2(self, so, qf, q, sor, updown, ibc=0):
         nst, JJ, II = so.shape
-        self.L.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, 0)
+        self.L.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, ibc)
 
     def setup_lines2(self, so, sor, d):
         nst, JJ, II = so.shape
@@ -267,38 +288,38 @@ class Ref:
         self.L.BMG2_SymStd_residual(i(0), _p(so), _p(qf), _p(q), _p(res), C.byref(u(II)), C.byref(u(JJ)),
                                     i(0), i(int(nst == 3)), i(nst), i(0), i(0), i(0), i(0))
 
-    def restrict2(self, q, qc, ci):
+    def restrict2(self, q, qc, ci, ibc=0):
         JJ, II = q.shape
         JJC, IIC = qc.shape
-        self.L.BMG2_SymStd_restrict(_p(q), _p(qc), _p(ci), II, JJ, IIC, JJC, 0)
+        self.L.BMG2_SymStd_restrict(_p(q), _p(qc), _p(ci), II, JJ, IIC, JJC, ibc)
 
-    def interp_add2(self, q, qc, res, so, ci):
+    def interp_add2(self, q, qc, res, so, ci, ibc=0):
         JJ, II = q.shape
         JJC, IIC = qc.shape
-        self.L.BMG2_SymStd_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ), so.shape[0], 0)
+        self.L.BMG2_SymStd_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ), so.shape[0], ibc)
 
-    def setup_interp2(self, so, ci):
+    def setup_interp2(self, so, ci, ibc=0):
         nst, JJ, II = so.shape
         _, JJC, IIC = ci.shape
         soc = np.zeros((5, JJC, IIC))
-        self.L.BMG2_SymStd_SETUP_interp_OI(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, 0, 0)
+        self.L.BMG2_SymStd_SETUP_interp_OI(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, ibc, 0)
 
-    def galerkin2(self, so, soc, ci):
+    def galerkin2(self, so, soc, ci, ibc=0):
         nst, JJ, II = so.shape
         _, JJC, IIC = ci.shape
-        self.L.BMG2_SymStd_SETUP_ITLI_ex(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, 0)
+        self.L.BMG2_SymStd_SETUP_ITLI_ex(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, ibc)
 
-    def setup_cg2(self, so, abd):
+    def setup_cg2(self, so, abd, ibc=0):
         nst, JJ, II = so.shape
         n2, n1 = abd.shape
         r = lambda v: C.byref(u(v))
-        self.L.BMG2_SymStd_SETUP_cg_LU(_p(so), r(II), r(JJ), C.byref(C.c_int(nst)), _p(abd), r(n1), r(n2), C.byref(C.c_int(0)))
+        self.L.BMG2_SymStd_SETUP_cg_LU(_p(so), r(II), r(JJ), C.byref(C.c_int(nst)), _p(abd), r(n1), r(n2), C.byref(C.c_int(ibc)))
 
-    def solve_cg2(self, q, qf, abd):
+    def solve_cg2(self, q, qf, abd, ibc=0):
         JJ, II = q.shape
         n2, n1 = abd.shape
         bbd = np.zeros(n2)
-        self.L.BMG2_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2), 0)
+        self.L.BMG2_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2), ibc)
 
     def setup_recip3(self, so, sor):
         nst, KK, JJ, II = so.shape
