@@ -139,6 +139,9 @@ typedef struct orc_ml orc_ml;
 orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
                       int relax, int nrelax_pre, int nrelax_post, int min_coarse,
                       int num_levels);
+orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                         int relax, int nrelax_pre, int nrelax_post, int min_coarse,
+                         int num_levels, int ibc);
 void orc_ml_destroy(orc_ml *ml);
 int orc_ml_nlevels(const orc_ml *ml);
 void orc_ml_level_dims(const orc_ml *ml, int lvl, len_t *nx, len_t *ny, len_t *nz);

@@ -38,8 +38,13 @@ def seq_l2(v):
 class RefML:
     """multilevel::setup + vcycle + solve composed from the Fortran kernels."""
 
-    def __init__(self, R, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, cycle="v"):
+    def __init__(self, R, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, cycle="v", ibc=0):
+        """ibc != 0 (2D, point relaxation): the reference's periodic branches; the bindings pass the same
+        code to every kernel (include/cedar/2d/relax.h:97, coarsen.h:57, src/2d/interp.cc:41-102 ...) and
+        the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)"""
         self.R, self.relax, self.pre, self.post, self.cycle = R, relax, nrelax_pre, nrelax_post, cycle
+        self.ibc = ibc
+        assert ibc == 0 or (so.ndim == 3 and relax == "point")
         self.nd = nd = so.ndim - 1
         n = [s - 2 for s in so.shape[1:]][::-1]  # nx, ny[, nz]
         ng = 0
@@ -61,7 +66,11 @@ class RefML:
                 self.b.append(np.zeros(shp))
         for l in range(ng - 1):
             F, K, Pm = self.A[l], self.A[l + 1], self.P[l + 1]
-            if nd == 2:
+            if nd == 2 and ibc:
+                R.setup_interp2(F, Pm, ibc=ibc)
+                R.galerkin2(F, K, Pm, ibc=ibc)
+                R.setup_recip2(F, self.SOR[l][0])
+            elif nd == 2:
                 R.setup_interp2(F, Pm)
                 R.galerkin2(F, K, Pm)
                 if relax == "point":
@@ -79,7 +88,10 @@ class RefML:
                 R.setup_recip3(F, self.SOR[l][0])
         C = self.A[-1]
         cs = [s - 2 for s in C.shape[1:]][::-1]
-        if nd == 2:
+        if nd == 2 and ibc:
+            self.abd = np.zeros((cs[0] * cs[1], cs[0] * cs[1]))
+            R.setup_cg2(C, self.abd, ibc=ibc)
+        elif nd == 2:
             self.abd = np.zeros((cs[0] * cs[1], cs[0] + 2))
             R.setup_cg2(C, self.abd)
         else:
@@ -91,6 +103,8 @@ class RefML:
         for _ in range(n):
             if self.nd == 3:
                 R.relax3(A, b, x, S[0], ud)
+            elif self.ibc:
+                R.relax2(A, b, x, S[0], ud, ibc=self.ibc)
             elif self.relax == "point":
                 R.relax2(A, b, x, S[0], ud)
             elif self.relax == "line-x":
@@ -112,14 +126,15 @@ class RefML:
         self._smooth(l, x, b, DOWN, self.pre)
         self._residual(l, x, b, self.res[l])
         cx, cb, Pm = self.x[l + 1], self.b[l + 1], self.P[l + 1]
-        (R.restrict2 if self.nd == 2 else R.restrict3)(self.res[l], cb, Pm)
+        kw = dict(ibc=self.ibc) if self.ibc else {}
+        (R.restrict2 if self.nd == 2 else R.restrict3)(self.res[l], cb, Pm, **kw)
         cx[...] = 0.0
         if l + 1 == self.nlev - 1:
-            (R.solve_cg2 if self.nd == 2 else R.solve_cg3)(cx, cb, self.abd)
+            (R.solve_cg2 if self.nd == 2 else R.solve_cg3)(cx, cb, self.abd, **kw)
         else:
             self._cycle(l + 1, cx, cb)
         if self.nd == 2:
-            R.interp_add2(x, cx, self.res[l], self.A[l], Pm)
+            R.interp_add2(x, cx, self.res[l], self.A[l], Pm, **kw)
         else:
             R.interp_add3(x, cx, self.A[l], self.res[l], Pm)
         self._smooth(l, x, b, UP, self.post)
@@ -143,7 +158,8 @@ class RefML:
 
     def vcycle(self, x, b):
         if self.nlev == 1:
-            (self.R.solve_cg2 if self.nd == 2 else self.R.solve_cg3)(x, b, self.abd)
+            kw = dict(ibc=self.ibc) if self.ibc else {}
+            (self.R.solve_cg2 if self.nd == 2 else self.R.solve_cg3)(x, b, self.abd, **kw)
         elif self.cycle == "f":
             self._fmg(0, x, b)
         else:
@@ -197,7 +213,36 @@ def main():
         print(name, ml.nlev, h[0], h[1:4], flush=True)
     with open(os.path.join(GOLD, "solves.json"), "w") as f:
         json.dump(hist, f, indent=1)
+    main_periodic(R)
+
+
+def main_periodic(R):
+    """2D periodic boundary conditions: kernel outputs, coarse solves and residual histories"""
+    kp = {}
+    for c in cases.CASES_PER:
+        for k, v in cases.kernel_suite_per(R, c).items():
+            kp[f"{c[0]}/{k}"] = v
+    for c in cases.CG_PER:
+        for k, v in cases.coarse_solve_per(R, c).items():
+            kp[f"{c[0]}/{k}"] = v
+    np.savez_compressed(os.path.join(GOLD, "periodic2d.npz"), **kp)
+    hist = {}
+    for name, (mk_op, mk_rhs, st) in cases.SOLVES_PER.items():
+        so, b = mk_op(), mk_rhs()
+        ml = RefML(R, so, **st)
+        x = np.zeros_like(b)
+        h = ml.solve(b, x, maxiter=10, tol=1e-8)
+        inner = x[1:-1, 1:-1]
+        hist[name] = {"settings": st, "nlevels": ml.nlev, "res0_l2": repr(h[0]), "rel_l2": [repr(v) for v in h[1:]],
+                      "x_l2": repr(seq_l2(x)), "x_sum": repr(float(np.cumsum(inner.ravel())[-1]))}
+        print(name, ml.nlev, h[0], h[1:4], flush=True)
+    with open(os.path.join(GOLD, "solves_periodic.json"), "w") as f:
+        json.dump(hist, f, indent=1)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "periodic":  # regenerate only the periodic fixtures
+        os.makedirs(GOLD, exist_ok=True)
+        main_periodic(Ref())
+    else:
+        main()

@@ -25,6 +25,7 @@ typedef struct {
 
 struct orc_ml {
 	int nd, nlev, relax, nrelax_pre, nrelax_post, cycle;
+	int ibc;              /* 0 Dirichlet; 2D only: 1 per_y, 2 per_x, 3 per_xy (BMG_get_bc.f90:13-16) */
 	orc_level *lv;
 	real_t *ABD, *bbd;
 	len_t nabd1, nabd2;
@@ -73,7 +74,18 @@ orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const 
                       int relax, int nrelax_pre, int nrelax_post, int min_coarse,
                       int num_levels)
 {
+	return orc_ml_create_bc(nd, nx, ny, nz, nstencil, so, relax, nrelax_pre, nrelax_post, min_coarse, num_levels, 0);
+}
+
+/* ibc != 0: the kernels' periodic branches (2D, point relaxation); the coarsest operator becomes a
+ * dense matrix, ABD(nxc*nyc, nxc*nyc) (include/cedar/2d/solver.h:110-114) */
+orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                         int relax, int nrelax_pre, int nrelax_post, int min_coarse,
+                         int num_levels, int ibc)
+{
+	if (ibc != 0 && (nd != 2 || relax != ORC_RELAX_POINT)) return NULL;
 	orc_ml *ml = (orc_ml *)calloc(1, sizeof(orc_ml));
+	ml->ibc = ibc;
 	ml->nd = nd; ml->relax = relax;
 	ml->nrelax_pre = nrelax_pre; ml->nrelax_post = nrelax_post;
 	int nlev = compute_num_levels(nd, nx, ny, nz, min_coarse);
@@ -92,7 +104,7 @@ orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const 
 		level_init(&ml->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, 1);
 	}
 	orc_level *C = &ml->lv[nlev - 1];
-	if (nd == 2) { ml->nabd1 = C->nx + 2; ml->nabd2 = C->nx * C->ny; }
+	if (nd == 2) { ml->nabd1 = ibc ? C->nx * C->ny : C->nx + 2; ml->nabd2 = C->nx * C->ny; }
 	else { ml->nabd1 = C->nx * (C->ny + 1) + 2; ml->nabd2 = C->nx * C->ny * C->nz; }
 	ml->ABD = zalloc((size_t)ml->nabd1 * ml->nabd2);
 	ml->bbd = zalloc(ml->nabd2);
@@ -101,7 +113,11 @@ orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const 
 	for (int l = 0; l < nlev - 1; l++) {
 		orc_level *F = &ml->lv[l], *K = &ml->lv[l + 1];
 		int ifd = (nd == 2) ? (F->nst == 3) : (F->nst == 4);
-		if (nd == 2) {
+		if (nd == 2 && ibc) {
+			orc2_setup_interp_per(F->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd, ibc);
+			orc2_galerkin_per(F->A, K->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd, ibc);
+			orc2_setup_recip(F->A, F->SOR0, F->II, F->JJ);
+		} else if (nd == 2) {
 			orc2_setup_interp(F->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd);
 			orc2_galerkin(F->A, K->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd);
 			switch (relax) {
@@ -119,7 +135,8 @@ orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const 
 		}
 	}
 	/* setup_cg_solve (multilevel.h:95-103) */
-	if (nd == 2) orc2_setup_cg(C->A, C->II, C->JJ, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
+	if (nd == 2 && ibc) orc2_setup_cg_per(C->A, C->II, C->JJ, C->nst, ml->ABD, ml->nabd1, ibc);
+	else if (nd == 2) orc2_setup_cg(C->A, C->II, C->JJ, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
 	else orc3_setup_cg(C->A, C->II, C->JJ, C->KK, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
 	return ml;
 }
@@ -169,6 +186,10 @@ static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, i
 			continue;
 		}
 		int ifd = L->nst == 3;
+		if (ml->ibc) {
+			orc2_relax_gs_per(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown, ml->ibc);
+			continue;
+		}
 		switch (ml->relax) {
 		case ORC_RELAX_POINT: orc2_relax_gs(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown); break;
 		case ORC_RELAX_LINE_X: orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown); break;
@@ -188,7 +209,8 @@ static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, i
 static void coarse_solve(orc_ml *ml, real_t *x, const real_t *b)
 {
 	orc_level *C = &ml->lv[ml->nlev - 1];
-	if (ml->nd == 2) orc2_solve_cg(x, b, C->II, C->JJ, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
+	if (ml->nd == 2 && ml->ibc) orc2_solve_cg_per(x, b, C->II, C->JJ, ml->ABD, ml->bbd, ml->nabd1, ml->ibc);
+	else if (ml->nd == 2) orc2_solve_cg(x, b, C->II, C->JJ, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
 	else orc3_solve_cg(x, b, C->II, C->JJ, C->KK, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
 }
 
@@ -198,12 +220,14 @@ static void ncycle(orc_ml *ml, int lvl, real_t *x, const real_t *b)
 	orc_level *L = &ml->lv[lvl], *K = &ml->lv[lvl + 1];
 	smooth(ml, L, x, b, BMG_DOWN, ml->nrelax_pre);
 	residual(ml, L, x, b, L->res);
-	if (ml->nd == 2) orc2_restrict(L->res, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
+	if (ml->nd == 2 && ml->ibc) orc2_restrict_per(L->res, K->b, K->P, L->II, L->JJ, K->II, K->JJ, ml->ibc);
+	else if (ml->nd == 2) orc2_restrict(L->res, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
 	else orc3_restrict(L->res, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK);
 	memset(K->x, 0, K->npts * sizeof(real_t)); /* coarse_x.set(0.0) */
 	if (lvl + 1 == ml->nlev - 1) coarse_solve(ml, K->x, K->b);
 	else ncycle(ml, lvl + 1, K->x, K->b);
-	if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
+	if (ml->nd == 2 && ml->ibc) orc2_interp_add_per(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ, ml->ibc);
+	else if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
 	else orc3_interp_add(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK);
 	smooth(ml, L, x, b, BMG_UP, ml->nrelax_post);
 }

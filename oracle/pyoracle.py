@@ -200,7 +200,7 @@ class Oracle:
         return self.L.orc_l2_norm3(_p(v), u(v.shape[2]), u(v.shape[1]), u(v.shape[0]))
 
     # ---------------- multilevel ----------------
-    def ml_create(self, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, num_levels=-1, cycle="v"):
+    def ml_create(self, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, num_levels=-1, cycle="v", ibc=0):
         nd = so.ndim - 1
         if nd == 2:
             nst, JJ, II = so.shape
@@ -208,8 +208,11 @@ class Oracle:
         else:
             nst, KK, JJ, II = so.shape
             nx, ny, nz = II - 2, JJ - 2, KK - 2
-        h = self.L.orc_ml_create(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
-                                 nrelax_pre, nrelax_post, min_coarse, num_levels)
+        self.L.orc_ml_create_bc.restype = C.c_void_p
+        h = self.L.orc_ml_create_bc(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
+                                    nrelax_pre, nrelax_post, min_coarse, num_levels, ibc)
+        if not h:
+            raise ValueError("periodic boundary conditions: 2D point relaxation only")
         m = MLHandle(self, h, nd)
         if cycle == "f":
             self.L.orc_ml_set_cycle(m.h, 1)

@@ -192,3 +192,80 @@ SOLVES = {
 # absolute floor (in units of ||r0||) below which residual histories of two
 # correctly-rounded implementations may differ: eps * cond-ish.  Default 1e-14.
 HIST_ATOL = {"aniso9_512_linexy": 1e-12, "stretch5_800x200_linex": 1e-12, "stretch5_200x800_liney": 1e-12}
+
+
+# --------------------------------------------------------------------------
+# 2D periodic boundary conditions: kernels with random ghosts, and full solves
+# --------------------------------------------------------------------------
+CASES_PER = [
+    # (name, nx, ny, nst, ibc)
+    ("p9x9_5_x", 9, 9, 3, 2), ("p9x9_9_y", 9, 9, 5, 1), ("p16x16_9_xy", 16, 16, 5, 3),
+    ("p17x12_9_x", 17, 12, 5, 2), ("p12x17_5_xy", 12, 17, 3, 3), ("p31x20_9_y", 31, 20, 5, 1),
+    ("p8x8_5_y", 8, 8, 3, 1), ("p6x7_9_xy", 6, 7, 5, 3), ("p64x48_9_x", 64, 48, 5, 2),
+]
+
+
+def kernel_suite_per(impl, case):
+    name, nx, ny, nst, ibc = case
+    sd = _seed(name)
+    g = (ny + 2, nx + 2)
+    gc = pb.coarse_shape(g)
+    so = pb.random_op(g, nst, sd, zero_ghost=False)
+    out = {}
+    sor = np.zeros((2,) + g)
+    impl.setup_recip2(so, sor)
+    qf, q = pb.uniform(g, sd + 1, -1, 1), pb.uniform(g, sd + 2, -1, 1)
+    for ud in (DOWN, UP):
+        impl.relax2(so, qf, q, sor, ud, ibc=ibc)
+        out[f"relax{ud}"] = q.copy()
+    ci = np.zeros((8,) + gc)
+    impl.setup_interp2(so, ci, ibc=ibc)
+    out["interp"] = ci.copy()
+    soc = np.zeros((5,) + gc)
+    impl.galerkin2(so, soc, ci, ibc=ibc)
+    out["galerkin"] = soc.copy()
+    r, qc = pb.uniform(g, sd + 3, -1, 1), np.zeros(gc)
+    impl.restrict2(r, qc, ci, ibc=ibc)
+    out["restrict_qc"], out["restrict_q"] = qc.copy(), r.copy()
+    x, xc, res = pb.uniform(g, sd + 4, -1, 1), pb.uniform(gc, sd + 5, -1, 1), pb.uniform(g, sd + 6, -1, 1)
+    impl.interp_add2(x, xc, res, so, ci, ibc=ibc)
+    out["interp_add_q"], out["interp_add_res"] = x.copy(), res.copy()
+    return out
+
+
+CG_PER = [("c3x3_5_x", 3, 3, 3, 2), ("c4x3_9_y", 4, 3, 5, 1), ("c3x5_9_xy", 3, 5, 5, 3), ("c5x4_5_xy", 5, 4, 3, 3)]
+
+
+def coarse_solve_per(impl, case):
+    name, nx, ny, nst, ibc = case
+    sd = _seed(name)
+    g = (ny + 2, nx + 2)
+    so = pb.random_op(g, nst, sd, zero_ghost=False)
+    so[0] *= 4.0  # keep the wrapped matrix positive definite
+    n = nx * ny
+    abd = np.zeros((n, n))
+    impl.setup_cg2(so, abd, ibc=ibc)
+    q = pb.uniform(g, sd + 2, -1, 1)
+    impl.solve_cg2(q, pb.uniform(g, sd + 1, -1, 1), abd, ibc=ibc)
+    return {"abd_upper": abd.T[np.triu_indices(n)].copy(), "q": q}
+
+
+SOLVES_PER = {
+    # the reference's periodic example (examples/basic-2d-ser/periodic.cc with periodic-config.json:
+    # V(1,1), point relaxation, periodic in x) at two sizes, and wrapped random operators
+    "perpoisson5_x_300_v11": (lambda: pb.periodic_poisson2(300, 300, (True, False)),
+                              lambda: pb.periodic_rhs2(300, 300, (True, False)),
+                              dict(relax="point", nrelax_pre=1, nrelax_post=1, ibc=2)),
+    "perpoisson5_y_128x96_v21": (lambda: pb.periodic_poisson2(128, 96, (False, True)),
+                                 lambda: pb.periodic_rhs2(128, 96, (False, True)),
+                                 dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=1)),
+    "perrand9_xy_96x80_v21": (lambda: pb.periodic_random_op(96, 80, 5, (True, True), 5),
+                              lambda: pb.periodic_rhs2(96, 80, (True, True)),
+                              dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=3)),
+    "perrand9_x_100x75_v21": (lambda: pb.periodic_random_op(100, 75, 5, (True, False), 6),
+                              lambda: pb.periodic_rhs2(100, 75, (True, False)),
+                              dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=2)),
+    "perrand5_xy_64_v21": (lambda: pb.periodic_random_op(64, 64, 3, (True, True), 7),
+                           lambda: pb.periodic_rhs2(64, 64, (True, True)),
+                           dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=3)),
+}

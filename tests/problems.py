@@ -201,3 +201,65 @@ def random_op(shape_g, nst, seed, zero_ghost=True):
 
 def coarse_shape(shape_g):
     return tuple(int((n - 2 - 1) / 2.0 + 1) + 2 for n in shape_g)
+
+
+# --------------------------------------------------------------------------
+# periodic problems
+# --------------------------------------------------------------------------
+def ibc_of(per):
+    """(periodic_x, periodic_y) -> ibc as BMG_get_bc maps the mask (src/2d/ftn/BMG_get_bc.f90:13-16 with
+    include/cedar/2d/ftn/BMG_parameters_c.h:193-196): x -> 2, y -> 1, both -> 3"""
+    return {(False, False): 0, (True, False): 2, (False, True): 1, (True, True): 3}[(bool(per[0]), bool(per[1]))]
+
+
+def periodic_poisson2(nx, ny, per):
+    """five-point operator of examples/basic-2d-ser/periodic.cc:17-84 (create_op): mesh widths from
+    nx-1 / ny-1 in a periodic direction, W / S entries also on the first row / column there, ghost
+    columns / rows filled with the periodic image"""
+    so = np.zeros((3, ny + 2, nx + 2))
+    mx, my = nx - (1 if per[0] else 0), ny - (1 if per[1] else 0)
+    hx, hy = 1.0 / (mx + 1), 1.0 / (my + 1)
+    xh, yh = hy / hx, hx / hy
+    ibeg, jbeg = (1 if per[0] else 2), (1 if per[1] else 2)
+    so[2, jbeg:ny + 1, 1:nx + 1] = 1.0 * yh
+    so[1, 1:ny + 1, ibeg:nx + 1] = 1.0 * xh
+    so[0, 1:ny + 1, 1:nx + 1] = 2 * xh + 2 * yh
+    if per[0]:
+        so[:, 1:ny + 1, ibeg - 1] = so[:, 1:ny + 1, nx]
+        so[:, 1:ny + 1, nx + 1] = so[:, 1:ny + 1, ibeg]
+    if per[1]:
+        so[:, jbeg - 1, 1:nx + 1] = so[:, ny, 1:nx + 1]
+        so[:, ny + 1, 1:nx + 1] = so[:, jbeg, 1:nx + 1]
+    return so
+
+
+def periodic_rhs2(nx, ny, per):
+    """set_problem of the same example (:87-125)"""
+    mx, my = nx - (1 if per[0] else 0), ny - (1 if per[1] else 0)
+    hx, hy = 1.0 / (mx + 1), 1.0 / (my + 1)
+    h2 = hx * hy
+    b = np.zeros((ny + 2, nx + 2))
+    i = np.arange(1, nx + 1)[None, :]
+    j = np.arange(1, ny + 1)[:, None]
+    b[1:ny + 1, 1:nx + 1] = 8 * (np.pi * np.pi) * np.sin(2 * np.pi * (i * hx)) * np.sin(2 * np.pi * (j * hy)) * h2
+    if per[0]:
+        b[:, 0] = b[:, nx]
+        b[:, nx + 1] = b[:, 1]
+    if per[1]:
+        b[0, :] = b[ny, :]
+        b[ny + 1, :] = b[1, :]
+    return b
+
+
+def periodic_random_op(nx, ny, nst, per, seed):
+    """strictly diagonally dominant random operator (definite also when both directions wrap) whose
+    ghost layers carry the periodic image in the wrapped directions and zeros on Dirichlet sides"""
+    g = (ny + 2, nx + 2)
+    so = random_op(g, nst, seed)
+    if per[0]:
+        so[:, :, 0] = so[:, :, nx]
+        so[:, :, nx + 1] = so[:, :, 1]
+    if per[1]:
+        so[:, 0, :] = so[:, ny, :]
+        so[:, ny + 1, :] = so[:, 1, :]
+    return so
