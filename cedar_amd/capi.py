@@ -138,9 +138,11 @@ class Kernels:
         nst, JJ, II = so.shape
         lib.BMG2_SymStd_SETUP_recip(_p(so), _p(sor), u(II), u(JJ), nst, 2)
 
-    def relax2(self, so, qf, q, sor, updown):
+    # ibc: the boundary code the reference's bindings obtain from BMG_get_bc(per_mask) and hand to every
+    # kernel (0 definite, 1 periodic in y, 2 in x, 3 in both; include/cedar/2d/relax.h:97 ...)
+    def relax2(self, so, qf, q, sor, updown, ibc=0):
         nst, JJ, II = so.shape
-        lib.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, 0)
+        lib.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, ibc)
 
     def setup_lines2(self, so, sor, d):
         nst, JJ, II = so.shape
@@ -166,37 +168,37 @@ class Kernels:
         nst, KK, JJ, II = so.shape
         lib.cedar_amd_matvec3(_p(so), _p(q), _p(qf), u(II), u(JJ), u(KK), nst)
 
-    def restrict2(self, q, qc, ci):
+    def restrict2(self, q, qc, ci, ibc=0):
         JJ, II = q.shape
         JJC, IIC = qc.shape
-        lib.BMG2_SymStd_restrict(_p(q), _p(qc), _p(ci), II, JJ, IIC, JJC, 0)
+        lib.BMG2_SymStd_restrict(_p(q), _p(qc), _p(ci), II, JJ, IIC, JJC, ibc)
 
-    def interp_add2(self, q, qc, res, so, ci):
+    def interp_add2(self, q, qc, res, so, ci, ibc=0):
         JJ, II = q.shape
         JJC, IIC = qc.shape
-        lib.BMG2_SymStd_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ), so.shape[0], 0)
+        lib.BMG2_SymStd_interp_add(_p(q), _p(qc), _p(res), _p(so), _p(ci), u(IIC), u(JJC), u(II), u(JJ), so.shape[0], ibc)
 
-    def setup_interp2(self, so, ci):
+    def setup_interp2(self, so, ci, ibc=0):
         nst, JJ, II = so.shape
         _, JJC, IIC = ci.shape
-        lib.BMG2_SymStd_SETUP_interp_OI(_p(so), None, _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, 0, 0)
+        lib.BMG2_SymStd_SETUP_interp_OI(_p(so), None, _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, ibc, 0)
 
-    def galerkin2(self, so, soc, ci):
+    def galerkin2(self, so, soc, ci, ibc=0):
         nst, JJ, II = so.shape
         _, JJC, IIC = ci.shape
-        lib.BMG2_SymStd_SETUP_ITLI_ex(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, 0)
+        lib.BMG2_SymStd_SETUP_ITLI_ex(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), nst, ibc)
 
-    def setup_cg2(self, so, abd):
+    def setup_cg2(self, so, abd, ibc=0):
         nst, JJ, II = so.shape
         n2, n1 = abd.shape
         r = lambda v: C.byref(u(v))
-        lib.BMG2_SymStd_SETUP_cg_LU(_p(so), r(II), r(JJ), C.byref(C.c_int(nst)), _p(abd), r(n1), r(n2), C.byref(C.c_int(0)))
+        lib.BMG2_SymStd_SETUP_cg_LU(_p(so), r(II), r(JJ), C.byref(C.c_int(nst)), _p(abd), r(n1), r(n2), C.byref(C.c_int(ibc)))
 
-    def solve_cg2(self, q, qf, abd):
+    def solve_cg2(self, q, qf, abd, ibc=0):
         JJ, II = q.shape
         n2, n1 = abd.shape
         bbd = np.zeros(n2)
-        lib.BMG2_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2), 0)
+        lib.BMG2_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), _p(abd), _p(bbd), u(n1), u(n2), ibc)
 
     # ---- 3D
     def setup_recip3(self, so, sor):

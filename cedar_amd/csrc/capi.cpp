@@ -74,6 +74,17 @@ static void report(const char *msg)
 	print_error(buf);
 }
 
+// 2D kernels with a periodic branch on the GPU path: |jpn| in {1 per_y, 2 per_x, 3 per_xy}.  Returns
+// -1 after reporting when the code is not served (indefinite variants, 3D codes), else |jpn|.
+static int bc2(int jpn, const char *who)
+{
+	if (jpn >= 0 && jpn <= 3) return jpn;
+	char buf[200];
+	snprintf(buf, sizeof(buf), "%s: boundary code %d is not implemented on the GPU path (0 definite, 1..3 periodic y/x/xy)", who, jpn);
+	report(buf);
+	return -1;
+}
+
 static bool dirichlet(int jpn, const char *who)
 {
 	if (jpn == 0) return true;
@@ -199,7 +210,8 @@ void BMG2_SymStd_relax_GS(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR,
                           int kf, int ifd, int nstncl, int nsorv, int irelax_sym, int updown, int jpn)
 {
 	(void)nsorv;
-	if (!dirichlet(jpn, "BMG2_SymStd_relax_GS")) return;
+	const int ipn = bc2(jpn, "BMG2_SymStd_relax_GS");
+	if (ipn < 0) return;
 	size_t P = (size_t)II * JJ;
 	// reference branch: 9-point when K < KF or IFD != 1 (relax_GS.f90:89)
 	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
@@ -207,7 +219,10 @@ void BMG2_SymStd_relax_GS(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR,
 	// NONSYM always uses the DOWN ordering (relax_GS.f90:78-87)
 	int ud = (irelax_sym == 0) ? BMG_DOWN : updown;
 	Staged sso(SO, P * nstncl, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
-	relax2_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+	if (ipn == 0)
+		relax2_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+	else if (relax2_gs_per(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, ipn, current_stream()))
+		report("BMG2_SymStd_relax_GS: periodic rows longer than 8192 points are not supported");
 }
 
 void BMG2_SymStd_residual(int *k, real_t *SO, real_t *QF, real_t *Q, real_t *RES, len_t *II, len_t *JJ,
@@ -273,39 +288,51 @@ void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t 
 
 void BMG2_SymStd_restrict(real_t *Q, real_t *QC, real_t *CI, int Nx, int Ny, int Nxc, int Nyc, int jpn)
 {
-	if (!dirichlet(jpn, "BMG2_SymStd_restrict")) return;
+	const int ipn = bc2(jpn, "BMG2_SymStd_restrict");
+	if (ipn < 0) return;
 	size_t P = (size_t)Nx * Ny, PC = (size_t)Nxc * Nyc;
-	Staged sq(Q, P, true, false), sqc(QC, PC, true, true), sci(CI, PC * 8, true, false);
-	restrict2(sq.get(), sqc.get(), sci.get(), Nx, Ny, Nxc, Nyc, current_stream());
+	// the periodic branch refreshes the fine vector's ghosts in place (restrict.f90:100-111)
+	Staged sq(Q, P, true, ipn != 0), sqc(QC, PC, true, true), sci(CI, PC * 8, true, false);
+	if (ipn == 0) restrict2(sq.get(), sqc.get(), sci.get(), Nx, Ny, Nxc, Nyc, current_stream());
+	else restrict2_per(sq.get(), sqc.get(), sci.get(), Nx, Ny, Nxc, Nyc, ipn, current_stream());
 }
 
 void BMG2_SymStd_interp_add(real_t *Q, real_t *QC, real_t *RES, real_t *SO, real_t *CI,
                             len_t IIC, len_t JJC, len_t IIF, len_t JJF, int nstncl, int jpn)
 {
-	if (!dirichlet(jpn, "BMG2_SymStd_interp_add")) return;
+	const int ipn = bc2(jpn, "BMG2_SymStd_interp_add");
+	if (ipn < 0) return;
 	size_t P = (size_t)IIF * JJF, PC = (size_t)IIC * JJC;
 	Staged sq(Q, P, true, true), sqc(QC, PC, true, false), sr(RES, P, true, true),
 	    sso(SO, P * nstncl, true, false), sci(CI, PC * 8, true, false);
-	interp_add2(sq.get(), sqc.get(), sr.get(), sso.get(), sci.get(), (int)IIC, (int)JJC, (int)IIF, (int)JJF, current_stream());
+	if (ipn == 0)
+		interp_add2(sq.get(), sqc.get(), sr.get(), sso.get(), sci.get(), (int)IIC, (int)JJC, (int)IIF, (int)JJF, current_stream());
+	else
+		interp_add2_per(sq.get(), sqc.get(), sr.get(), sso.get(), sci.get(), (int)IIC, (int)JJC, (int)IIF, (int)JJF, ipn,
+		                current_stream());
 }
 
 void BMG2_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf,
                                  len_t iic, len_t jjc, int ifd, int nstncl, int jpn, int irelax)
 {
 	(void)soc; (void)irelax;
-	if (!dirichlet(jpn, "BMG2_SymStd_SETUP_interp_OI")) return;
+	const int ipn = bc2(jpn, "BMG2_SymStd_SETUP_interp_OI");
+	if (ipn < 0) return;
 	size_t P = (size_t)iif * jjf, PC = (size_t)iic * jjc;
 	Staged sso(so, P * nstncl, true, false), sci(ci, PC * 8, true, true);
-	setup_interp2(sso.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, current_stream());
+	if (ipn == 0) setup_interp2(sso.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, current_stream());
+	else setup_interp2_per(sso.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, ipn, current_stream());
 }
 
 void BMG2_SymStd_SETUP_ITLI_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf,
                                len_t iic, len_t jjc, int ifd, int nstncl, int ipn)
 {
-	if (!dirichlet(ipn, "BMG2_SymStd_SETUP_ITLI_ex")) return;
+	const int bc = bc2(ipn, "BMG2_SymStd_SETUP_ITLI_ex");
+	if (bc < 0) return;
 	size_t P = (size_t)iif * jjf, PC = (size_t)iic * jjc;
 	Staged sso(so, P * nstncl, true, false), ssoc(soc, PC * 5, true, true), sci(ci, PC * 8, true, false);
-	galerkin2(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, current_stream());
+	if (bc == 0) galerkin2(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, current_stream());
+	else galerkin2_per(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, bc, current_stream());
 }
 
 static void cg_info(int *dinfo, const char *who)
@@ -318,11 +345,13 @@ static void cg_info(int *dinfo, const char *who)
 void BMG2_SymStd_SETUP_cg_LU(real_t *so, len_t *ii, len_t *jj, int *nstncl, real_t *abd,
                              len_t *nabd1, len_t *nabd2, int *ibc)
 {
-	if (!dirichlet(*ibc, "BMG2_SymStd_SETUP_cg_LU")) return;
+	const int bc = bc2(*ibc, "BMG2_SymStd_SETUP_cg_LU");
+	if (bc < 0) return;
 	size_t P = (size_t)(*ii) * (*jj), NA = (size_t)(*nabd1) * (*nabd2);
 	Staged sso(so, P * (*nstncl), true, false), sabd(abd, NA, true, true);
 	int *dinfo = static_cast<int *>(pool_get(64));
-	setup_cg2(sso.get(), (int)*ii, (int)*jj, *nstncl, sabd.get(), (int)*nabd1, (int)*nabd2, dinfo, current_stream());
+	if (bc == 0) setup_cg2(sso.get(), (int)*ii, (int)*jj, *nstncl, sabd.get(), (int)*nabd1, (int)*nabd2, dinfo, current_stream());
+	else setup_cg2_per(sso.get(), (int)*ii, (int)*jj, *nstncl, sabd.get(), (int)*nabd1, bc, dinfo, current_stream());
 	cg_info(dinfo, "Coarse grid Cholesky decomp failed!");
 	pool_put(dinfo, 64);
 }
@@ -330,10 +359,12 @@ void BMG2_SymStd_SETUP_cg_LU(real_t *so, len_t *ii, len_t *jj, int *nstncl, real
 void BMG2_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, real_t *abd, real_t *bbd,
                           len_t nabd1, len_t nabd2, int ibc)
 {
-	if (!dirichlet(ibc, "BMG2_SymStd_SOLVE_cg")) return;
+	const int bc = bc2(ibc, "BMG2_SymStd_SOLVE_cg");
+	if (bc < 0) return;
 	size_t P = (size_t)ii * jj, NA = (size_t)nabd1 * nabd2;
 	Staged sq(q, P, true, true), sqf(qf, P, true, false), sabd(abd, NA, true, false), sb(bbd, nabd2, false, true);
-	solve_cg2(sq.get(), sqf.get(), (int)ii, (int)jj, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
+	if (bc == 0) solve_cg2(sq.get(), sqf.get(), (int)ii, (int)jj, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
+	else solve_cg2_per(sq.get(), sqf.get(), (int)ii, (int)jj, sabd.get(), sb.get(), (int)nabd1, bc, current_stream());
 }
 
 // ------------------------------------------------------------------ domain-decomposition pieces

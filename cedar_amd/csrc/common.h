@@ -66,6 +66,18 @@ void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int nstncl, hipStream_t st);
 void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int KK, int nstncl, hipStream_t st);
+// 2D periodic boundary conditions (periodic2d.hip); ipn = 1 per_y, 2 per_x, 3 per_xy
+void wrap2(real_t *q, int II, int JJ, int nplanes, int do_y, int do_x, hipStream_t st);
+int relax2_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                  int II, int JJ, int nstncl, int updown, int ipn, hipStream_t st); // 1 = rows too long
+void restrict2_per(real_t *q, real_t *qc, const real_t *ci, int Nx, int Ny, int Nxc, int Nyc, int ipn, hipStream_t st);
+void interp_add2_per(real_t *q, const real_t *qc, real_t *res, const real_t *so, const real_t *ci,
+                     int IIC, int JJC, int IIF, int JJF, int ipn, hipStream_t st);
+void galerkin2_per(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, int ipn,
+                   hipStream_t st);
+void setup_interp2_per(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, int ipn, hipStream_t st);
+void setup_cg2_per(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int ipn, int *info, hipStream_t st);
+void solve_cg2_per(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int ipn, hipStream_t st);
 // qf = A q (operator application with Cedar's sign convention), residual.hip
 void matvec2(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int nstncl, hipStream_t st);
 void matvec3(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int KK, int nstncl, hipStream_t st);

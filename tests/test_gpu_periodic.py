@@ -1,0 +1,67 @@
+"""2D periodic boundary conditions on the GPU path, through the C ABI with the boundary
+code the reference's bindings pass (jpn / ibc = 1, 2, 3), against the golden vectors the reference's
+Fortran produced (tests/golden/periodic2d.npz, solves_periodic.json) and against the oracle.
+Bit-exact for relax / restrict / interp_add / interpolation; rounding-level for what goes through
+the Galerkin product and the dense Cholesky."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import problems as pb
+from test_oracle_periodic import EXACT, check_kernels
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def K():
+    from cedar_amd import capi
+    assert capi.device_count() >= 1, "no GPU visible"
+    return capi.Kernels()
+
+
+@pytest.fixture(scope="module")
+def gper():
+    return np.load(os.path.join(HERE, "golden", "periodic2d.npz"))
+
+
+@pytest.mark.parametrize("case", cases.CASES_PER, ids=lambda c: c[0])
+def test_periodic_kernels_vs_golden(K, gper, case):
+    check_kernels(case[0], cases.kernel_suite_per(K, case), gper)
+
+
+@pytest.mark.parametrize("case", cases.CG_PER, ids=lambda c: c[0])
+def test_periodic_coarse_solve_vs_golden(K, gper, case):
+    check_kernels(case[0], cases.coarse_solve_per(K, case), gper)
+
+
+EXTRA = [("x300x7_9_x", 300, 7, 5, 2), ("x1030x5_9_xy", 1030, 5, 5, 3), ("x129x130_5_y", 129, 130, 3, 1),
+         ("x4x4_9_xy", 4, 4, 5, 3), ("x5x4_5_x", 5, 4, 3, 2), ("x600x33_5_xy", 600, 33, 3, 3)]
+
+
+@pytest.mark.parametrize("case", EXTRA, ids=lambda c: c[0])
+def test_periodic_kernels_vs_oracle(K, oracle, case):
+    got, want = cases.kernel_suite_per(K, case), cases.kernel_suite_per(oracle, case)
+    for k in want:
+        if k in EXACT:
+            assert np.array_equal(got[k], want[k]), (case[0], k, np.max(np.abs(got[k] - want[k])))
+        else:
+            assert np.max(np.abs(got[k] - want[k])) <= 1e-13 * np.max(np.abs(want[k])), (case[0], k)
+
+
+def test_periodic_lines_and_3d_are_refused_loudly(K, capfd):
+    g = (10, 12)
+    so, q = pb.random_op(g, 5, 1), pb.uniform(g, 2)
+    q0 = q.copy()
+    sor = np.zeros((2,) + g)
+    K.setup_lines2(so, sor, "x")
+    from cedar_amd import capi
+    import ctypes as C
+    u = C.c_uint
+    capi.lib.BMG2_SymStd_relax_lines_x(1, capi._p(so), capi._p(q), capi._p(q), capi._p(sor), None, u(12), u(10), 1, 0, 5, 1, 0, 2)
+    assert np.array_equal(q, q0)
+    assert "only Dirichlet" in capfd.readouterr().err
