@@ -49,7 +49,7 @@ lib.cedar_amd_set_stream.argtypes = [C.c_void_p]
 class Settings(C.Structure):
     _fields_ = [("relaxation", C.c_int), ("nrelax_pre", C.c_int), ("nrelax_post", C.c_int),
                 ("num_levels", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double),
-                ("min_coarse", C.c_int), ("cycle", C.c_int)]
+                ("min_coarse", C.c_int), ("cycle", C.c_int), ("ibc", C.c_int)]
 
 
 def device_count():
@@ -302,7 +302,7 @@ class Solver:
     """cedar::cdr2::solver / cdr3::solver on the device (include/cedar_amd.h, handle API)."""
 
     def __init__(self, so, relax="point", nrelax_pre=2, nrelax_post=1, num_levels=-1,
-                 max_iter=10, tol=1e-8, min_coarse=3, share_operator=False, cycle="v"):
+                 max_iter=10, tol=1e-8, min_coarse=3, share_operator=False, cycle="v", ibc=0):
         shp = so.shape
         self.nd = len(shp) - 1
         nst = shp[0]
@@ -310,7 +310,7 @@ class Solver:
         nz = shp[1] - 2 if self.nd == 3 else 1
         self.shape = tuple(shp[1:])
         st = Settings(RELAX[relax], nrelax_pre, nrelax_post, num_levels, max_iter, tol, min_coarse,
-                      {"v": 0, "f": 1}[cycle])
+                      {"v": 0, "f": 1}[cycle], ibc)
         self.max_iter = max_iter
         self._so = so if share_operator else None  # keep the shared operator alive
         self.h = lib.cedar_amd_solver_create(self.nd, nx, ny, nz, nst, _vp(so), int(share_operator), C.byref(st))

@@ -113,6 +113,10 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 			relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
 			continue;
 		}
+		if (s->st.ibc) { // periodic branch (point relaxation; enforced at create)
+			relax2_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, s->st.ibc, st);
+			continue;
+		}
 		switch (s->st.relaxation) {
 		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
 		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
@@ -132,7 +136,8 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 void coarse_solve(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 {
 	const Level &C = s->lv.back();
-	if (s->nd == 2) solve_cg2(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
+	if (s->nd == 2 && s->st.ibc) solve_cg2_per(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->st.ibc, st);
+	else if (s->nd == 2) solve_cg2(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
 	else solve_cg3(x, b, C.II, C.JJ, C.KK, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
 }
 
@@ -141,12 +146,14 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	Level &L = s->lv[lvl], &K = s->lv[lvl + 1];
 	smooth(s, L, x, b, BMG_DOWN, s->st.nrelax_pre, st);
 	residual(s, L, x, b, L.res, st);
-	if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
+	else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
 	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
 	CEDAR_HIP_CHECK(hipMemsetAsync(K.x, 0, K.npts * sizeof(real_t), st)); // coarse_x.set(0.0)
 	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
 	else ncycle(s, lvl + 1, K.x, K.b, st);
-	if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	if (s->nd == 2 && s->st.ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, s->st.ibc, st);
+	else if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
 	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
 	smooth(s, L, x, b, BMG_UP, s->st.nrelax_post, st);
 }
@@ -228,6 +235,7 @@ void cedar_amd_default_settings(cedar_amd_settings *s)
 	s->tol = 1e-8;
 	s->min_coarse = 3;
 	s->cycle = 0;
+	s->ibc = 0;
 }
 
 cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil,
@@ -243,6 +251,18 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		char msg[] = "cedar_amd_solver_create: 3D supports point relaxation only (plane relaxation is out of scope)";
 		print_error(msg);
 		s->st.relaxation = CEDAR_AMD_RELAX_POINT;
+	}
+	if (s->st.ibc != 0) {
+		// periodic boundary conditions: 2D, point relaxation, V-cycle, rows that fit the LDS window
+		const bool ok = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3 && s->st.relaxation == CEDAR_AMD_RELAX_POINT
+		                && s->st.cycle == 0 && (size_t)(nx + 2) * sizeof(real_t) <= 64 * 1024;
+		if (!ok) {
+			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for 2D point relaxation "
+			             "V-cycles (ibc 1..3, rows up to 8190 points); no solver created";
+			print_error(msg);
+			delete s;
+			return nullptr;
+		}
 	}
 	if (const char *e = getenv("CEDAR_AMD_NO_GRAPH")) s->use_graph = !(e[0] == '1');
 	int nlev = compute_num_levels(nd, nx, ny, nz, s->st.min_coarse);
@@ -272,7 +292,8 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		level_init(s->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, true, ly);
 	}
 	const Level &C = s->lv.back();
-	if (nd == 2) { s->nabd1 = C.nx + 2; s->nabd2 = C.nx * C.ny; }
+	// periodic: the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)
+	if (nd == 2) { s->nabd1 = s->st.ibc ? C.nx * C.ny : C.nx + 2; s->nabd2 = C.nx * C.ny; }
 	else { s->nabd1 = C.nx * (C.ny + 1) + 2; s->nabd2 = C.nx * C.ny * C.nz; }
 	s->ABD = dalloc((size_t)s->nabd1 * s->nabd2);
 	s->bbd = dalloc(s->nabd2);
@@ -284,8 +305,13 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		Level &F = s->lv[l], &K = s->lv[l + 1];
 		if (nd == 2) {
 			int ifd = F.nst == 3;
-			setup_interp2(F.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, st);
-			galerkin2(F.A, K.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, st);
+			if (s->st.ibc) {
+				setup_interp2_per(F.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, s->st.ibc, st);
+				galerkin2_per(F.A, K.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, s->st.ibc, st);
+			} else {
+				setup_interp2(F.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, st);
+				galerkin2(F.A, K.A, K.P, F.II, F.JJ, K.II, K.JJ, ifd, st);
+			}
 			switch (s->st.relaxation) {
 			case CEDAR_AMD_RELAX_POINT: setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, 1, st); break;
 			case CEDAR_AMD_RELAX_LINE_X: setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st); break;
@@ -301,7 +327,8 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 			setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, F.KK, st);
 		}
 	}
-	if (nd == 2) setup_cg2(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
+	if (nd == 2 && s->st.ibc) setup_cg2_per(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->st.ibc, s->dinfo, st);
+	else if (nd == 2) setup_cg2(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
 	else setup_cg3(C.A, C.II, C.JJ, C.KK, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
 	int info = 0;
 	CEDAR_HIP_CHECK(hipMemcpyAsync(&info, s->dinfo, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -258,7 +258,7 @@ public:
 		st.num_levels = settings.num_levels; st.max_iter = settings.maxiter; st.tol = settings.tol;
 		st.min_coarse = settings.min_coarse;
 		st.cycle = settings.cycle;
-		if (kman->get_params()->per_mask() != 0) log::error << "periodic boundaries are not implemented on the GPU path" << std::endl;
+		BMG_get_bc(kman->get_params()->per_mask(), &st.ibc); // grid.periodic -> boundary code, as every reference binding does
 		h = cedar_amd_solver_create(2, fop.shape(0), fop.shape(1), 1, stencil_ndirs<fsten>::value, fop.data(), 0, &st);
 	}
 	~solver() { cedar_amd_solver_destroy(h); }

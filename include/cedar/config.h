@@ -43,7 +43,12 @@ public:
 	}
 	template <class T> void set(const std::string & path, T v) { std::ostringstream o; o << v; scalars[path] = o.str(); }
 private:
-	template <class T> static T conv(const std::string & s) { std::istringstream i(s); T v{}; i >> v; return v; }
+	template <class T> static T conv(const std::string & s)
+	{
+		// JSON booleans read as numbers / bools (grid.periodic is an array of true/false)
+		std::istringstream i(s == "true" ? "1" : s == "false" ? "0" : s);
+		T v{}; i >> v; return v;
+	}
 	void ws() { while (pos < txt.size() && std::isspace((unsigned char)txt[pos])) pos++; }
 	std::string parse_string()
 	{

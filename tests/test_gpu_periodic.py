@@ -65,3 +65,38 @@ def test_periodic_lines_and_3d_are_refused_loudly(K, capfd):
     capi.lib.BMG2_SymStd_relax_lines_x(1, capi._p(so), capi._p(q), capi._p(q), capi._p(sor), None, u(12), u(10), 1, 0, 5, 1, 0, 2)
     assert np.array_equal(q, q0)
     assert "only Dirichlet" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("name", list(cases.SOLVES_PER), ids=str)
+def test_periodic_solve_history_vs_reference_golden(name, oracle):
+    """device-resident solver with ibc != 0 (hipGraph V-cycle): residual history of the reference's
+    periodic example problem and of wrapped random operators, iteration for iteration"""
+    from cedar_amd import capi
+    gold = json.load(open(os.path.join(HERE, "golden", "solves_periodic.json")))[name]
+    mk_op, mk_rhs, st = cases.SOLVES_PER[name]
+    so, b = mk_op(), mk_rhs()
+    s = capi.Solver(so, relax=st["relax"], nrelax_pre=st["nrelax_pre"], nrelax_post=st["nrelax_post"], ibc=st["ibc"])
+    assert s.nlevels() == gold["nlevels"]
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    want = [float(gold["res0_l2"])] + [float(v) for v in gold["rel_l2"]]
+    assert len(h) == len(want)
+    np.testing.assert_allclose(h, want, rtol=1e-10, atol=1e-14)
+    inner = x[1:-1, 1:-1]
+    assert abs(float(np.sqrt(np.cumsum((inner * inner).ravel())[-1])) - float(gold["x_l2"])) <= 1e-11 * float(gold["x_l2"])
+    # hierarchy against the oracle: interpolation bit-exact, coarse operators to rounding
+    ml = oracle.ml_create(so, **st)
+    for lvl in range(1, s.nlevels()):
+        P, Po = s.array(lvl, "P"), ml.array(lvl, "P")
+        assert np.array_equal(P, Po) or np.max(np.abs(P - Po)) <= 1e-13 * np.max(np.abs(Po)), lvl
+        A, Ao = s.array(lvl, "A"), ml.array(lvl, "A")
+        assert np.max(np.abs(A - Ao)) <= 1e-12 * np.max(np.abs(Ao)), lvl
+    ml.close()
+    s.close()
+
+
+def test_periodic_solver_refuses_lines(capfd):
+    from cedar_amd import capi
+    with pytest.raises(RuntimeError):
+        capi.Solver(pb.periodic_poisson2(32, 32, (True, False)), relax="line-x", ibc=2)
+    assert "periodic boundary conditions are implemented for 2D point relaxation" in capfd.readouterr().err
