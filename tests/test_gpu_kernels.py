@@ -121,8 +121,10 @@ def test_device_pointers_are_used_in_place(K):
     assert np.array_equal(d[2].numpy(), want)
 
 
-def test_periodic_is_refused_loudly(K, capfd):
-    """ibc != 0 is out of scope: the call reports through print_error and leaves q untouched"""
+def test_unserved_boundary_codes_are_refused_loudly(K, capfd):
+    """boundary codes the GPU path does not serve (indefinite variants < 0, 3D periodic codes) report
+    through print_error and leave q untouched; the 2D periodic codes 1..3 are served
+    (tests/test_gpu_periodic.py)"""
     import ctypes as C
     from cedar_amd import capi
     import problems as pb
@@ -131,6 +133,14 @@ def test_periodic_is_refused_loudly(K, capfd):
     q0 = q.copy()
     sor, qf = np.zeros((2,) + g), np.zeros(g)
     capi.lib.BMG2_SymStd_relax_GS(1, capi._p(so), capi._p(qf), capi._p(q), capi._p(sor), C.c_uint(8), C.c_uint(8),
-                                  1, 0, 5, 2, 1, 0, 3)
+                                  1, 0, 5, 2, 1, 0, -3)
     assert np.array_equal(q, q0)
+    assert "boundary code -3 is not implemented" in capfd.readouterr().err
+    g3 = (6, 6, 6)
+    so3, q3 = pb.random_op(g3, 14, 1), pb.uniform(g3, 2)
+    q30 = q3.copy()
+    sor3, qf3 = np.zeros((2,) + g3), np.zeros(g3)
+    capi.lib.BMG3_SymStd_relax_GS(1, capi._p(so3), capi._p(qf3), capi._p(q3), capi._p(sor3), C.c_uint(6), C.c_uint(6), C.c_uint(6),
+                                  0, 14, 2, 1, 0, 8)
+    assert np.array_equal(q3, q30)
     assert "Dirichlet" in capfd.readouterr().err
