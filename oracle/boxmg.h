@@ -85,6 +85,12 @@ void orc2_interp_add_per(real_t *q, const real_t *qc, real_t *res, const real_t 
                          const real_t *ci, len_t IIC, len_t JJC, len_t IIF, len_t JJF, int ipn);
 void orc2_galerkin_per(const real_t *so, real_t *soc, const real_t *ci, len_t IIF, len_t JJF,
                        len_t IIC, len_t JJC, int ifd, int ipn);
+void orc2_setup_lines_x_per(const real_t *so, real_t *sor, len_t II, len_t JJ, int ipn);
+void orc2_setup_lines_y_per(const real_t *so, real_t *sor, len_t II, len_t JJ, int ipn);
+void orc2_relax_lines_x_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *b,
+                            len_t II, len_t JJ, int ifd, int updown, int ipn);
+void orc2_relax_lines_y_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *b,
+                            len_t II, len_t JJ, int ifd, int updown, int ipn);
 int orc2_setup_cg_per(const real_t *so, len_t II, len_t JJ, int nstncl, real_t *abd, len_t nabd1, int ipn);
 int orc2_solve_cg_per(real_t *q, const real_t *qf, len_t II, len_t JJ,
                       const real_t *abd, real_t *bbd, len_t nabd1, int ipn);

@@ -1,11 +1,10 @@
 /* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's 2D periodic branches
  * (ibc = BMG_BCs_def_per_y 1, _per_x 2, _per_xy 3; include/cedar/2d/ftn/BMG_parameters_c.h:193-196),
- * point relaxation.  Each function cites the Fortran it follows; pinned bit for bit against
+ * point and line relaxation.  Each function cites the Fortran it follows; pinned bit for bit against
  * oracle/_ref (tests/test_oracle_periodic.py), except the dense Cholesky (vendor LAPACK vs the
  * unblocked netlib order restated in lapack_mini.c: rounding-level differences).
  * The interpolation set-up lives in boxmg2.c (orc2_setup_interp_per) next to the formulas it shares
- * with the non-periodic driver.  Periodic line relaxation (Sherman-Morrison closure of the cyclic
- * tridiagonals, BMG2_SymStd_relax_lines_x.f90:180-300) is not restated. */
+ * with the non-periodic driver. */
 #include "boxmg.h"
 #include <math.h>
 #include <string.h>
@@ -244,3 +243,133 @@ int orc2_solve_cg_per(real_t *q, const real_t *qf, len_t II, len_t JJ,
 	return 0;
 #undef ABD
 }
+
+/* ------------------------------------------------------------------ periodic line relaxation
+ * A line that closes on itself is a cyclic tridiagonal system; the reference folds the wrap-around
+ * coupling into the two end diagonals at set-up and corrects each solve with the Sherman-Morrison
+ * formula (a second DPTTRS with the rank-one column).  Lines in the non-periodic direction use the
+ * ordinary solve; only the ghost wraps differ. */
+#define SO(i, j, s) S2(so, II, JJ, i, j, s)
+#define Q(i, j) F2(q, II, i, j)
+#define QF(i, j) F2(qf, II, i, j)
+#define SORT(j, i, s) (sor)[(size_t)((j)-1) + (size_t)JJ * ((size_t)((i)-1) + (size_t)II * (size_t)(s))]
+
+/* src/2d/ftn/BMG2_SymStd_SETUP_lines_x.f90:68-87 */
+void orc2_setup_lines_x_per(const real_t *so, real_t *sor, len_t II, len_t JJ, int ipn)
+{
+	for (len_t j = 2; j <= JJ - 1; j++)
+		for (len_t i = 2; i <= II - 1; i++) {
+			S2(sor, II, JJ, i, j, 1) = -SO(i, j, KW);
+			S2(sor, II, JJ, i, j, 0) = SO(i, j, KO);
+		}
+	if (PER_X(ipn))
+		for (len_t j = 2; j <= JJ - 1; j++) {
+			S2(sor, II, JJ, 2, j, 0) = S2(sor, II, JJ, 2, j, 0) + SO(2, j, KW);
+			S2(sor, II, JJ, II - 1, j, 0) = S2(sor, II, JJ, II - 1, j, 0) + SO(II, j, KW);
+		}
+	for (len_t j = 2; j <= JJ - 1; j++)
+		orc_dpttrf((int)II - 2, &S2(sor, II, JJ, 2, j, 0), &S2(sor, II, JJ, 3, j, 1));
+}
+
+/* src/2d/ftn/BMG2_SymStd_SETUP_lines_y.f90:69-92 (SOR transposed) */
+void orc2_setup_lines_y_per(const real_t *so, real_t *sor, len_t II, len_t JJ, int ipn)
+{
+	for (len_t i = 2; i <= II - 1; i++)
+		for (len_t j = 2; j <= JJ - 1; j++) {
+			SORT(j, i, 1) = -SO(i, j, KS);
+			SORT(j, i, 0) = SO(i, j, KO);
+		}
+	if (PER_Y(ipn))
+		for (len_t i = 2; i <= II - 1; i++) {
+			SORT(2, i, 0) = SORT(2, i, 0) + SO(i, 2, KS);
+			SORT(JJ - 1, i, 0) = SORT(JJ - 1, i, 0) + SO(i, JJ, KS);
+		}
+	for (len_t i = 2; i <= II - 1; i++)
+		orc_dpttrf((int)JJ - 2, &SORT(2, i, 0), &SORT(3, i, 1));
+}
+
+/* src/2d/ftn/BMG2_SymStd_relax_lines_x.f90: ipn = per_y -> :75-176 (ordinary solves, one y wrap at the
+ * end); ipn = per_x / per_xy -> :178-300 (Sherman-Morrison, y then x wrap after each colour).
+ * b: scratch of II doubles. */
+void orc2_relax_lines_x_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *b,
+                            len_t II, len_t JJ, int ifd, int updown, int ipn)
+{
+	const int I1 = (int)II - 1, J1 = (int)JJ - 1;
+	const int jstart = updown == BMG_DOWN ? 3 : 2, jend = updown == BMG_DOWN ? 2 : 3, jstride = updown == BMG_DOWN ? -1 : 1;
+	if (!PER_X(ipn)) {
+		orc2_relax_lines_x(so, qf, q, sor, II, JJ, ifd, updown);
+		if (ipn == 1) wrap_y(q, II, JJ);
+		return;
+	}
+	for (int jbeg = jstart; jbeg != jend + jstride; jbeg += jstride) {
+		for (int j = jbeg; j <= J1; j += 2) {
+			for (int i = 2; i <= I1; i++) {
+				if (ifd != 1)
+					Q(i, j) = QF(i, j) + SO(i, j, KS) * Q(i, j - 1) + SO(i, j + 1, KS)
+					          * Q(i, j + 1) + SO(i, j, KSW) * Q(i - 1, j - 1) + SO(i + 1, j, KNW)
+					          * Q(i + 1, j - 1) + SO(i, j + 1, KNW) * Q(i - 1, j + 1)
+					          + SO(i + 1, j + 1, KSW) * Q(i + 1, j + 1);
+				else
+					Q(i, j) = QF(i, j) + SO(i, j, KS) * Q(i, j - 1) + SO(i, j + 1, KS) * Q(i, j + 1);
+			}
+			orc_dpttrs(I1 - 1, &S2(sor, II, JJ, 2, j, 0), &S2(sor, II, JJ, 3, j, 1), &Q(2, j));
+			for (int i = 2; i <= I1; i++) b[i - 1] = 0.0;
+			b[2 - 1] = -SO(2, j, KW);
+			b[I1 - 1] = -SO(II, j, KW);
+			orc_dpttrs(I1 - 1, &S2(sor, II, JJ, 2, j, 0), &S2(sor, II, JJ, 3, j, 1), &b[1]);
+			real_t alpha = b[2 - 1] + b[I1 - 1];
+			real_t beta = Q(2, j) + Q(I1, j);
+			beta = beta / (1.0 + alpha);
+			for (int i = 2; i <= I1; i++) Q(i, j) = Q(i, j) - beta * b[i - 1];
+		}
+		if (PER_Y(ipn)) wrap_y(q, II, JJ);
+		wrap_x(q, II, JJ);
+	}
+}
+
+/* src/2d/ftn/BMG2_SymStd_relax_lines_y.f90: ipn = per_x -> :77-176 (ordinary solves, one x wrap at the
+ * end); per_y / per_xy -> :178-300.  b: scratch of 2*JJ doubles. */
+void orc2_relax_lines_y_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *b,
+                            len_t II, len_t JJ, int ifd, int updown, int ipn)
+{
+	const int I1 = (int)II - 1, J1 = (int)JJ - 1;
+	const int istart = updown == BMG_DOWN ? 3 : 2, iend = updown == BMG_DOWN ? 2 : 3, istride = updown == BMG_DOWN ? -1 : 1;
+	if (!PER_Y(ipn)) {
+		orc2_relax_lines_y(so, qf, q, sor, b, II, JJ, ifd, updown);
+		if (ipn == 2) wrap_x(q, II, JJ);
+		return;
+	}
+	real_t *b2 = b + JJ; /* B(JJ+J) */
+	for (int ibeg = istart; ibeg != iend + istride; ibeg += istride) {
+		if (ifd == 1) /* five point: the right-hand sides of the whole colour first, in place (:262-268) */
+			for (int j = 2; j <= J1; j++)
+				for (int i = ibeg; i <= I1; i += 2)
+					Q(i, j) = QF(i, j) + SO(i, j, KW) * Q(i - 1, j) + SO(i + 1, j, KW) * Q(i + 1, j);
+		for (int i = ibeg; i <= I1; i += 2) {
+			for (int j = 2; j <= J1; j++) {
+				if (ifd != 1)
+					b[j - 1] = QF(i, j) + SO(i, j, KW) * Q(i - 1, j) + SO(i + 1, j, KW)
+					           * Q(i + 1, j) + SO(i, j, KSW) * Q(i - 1, j - 1) + SO(i + 1, j, KNW)
+					           * Q(i + 1, j - 1) + SO(i, j + 1, KNW) * Q(i - 1, j + 1)
+					           + SO(i + 1, j + 1, KSW) * Q(i + 1, j + 1);
+				else
+					b[j - 1] = Q(i, j);
+			}
+			orc_dpttrs(J1 - 1, &SORT(2, i, 0), &SORT(3, i, 1), &b[1]);
+			for (int j = 2; j <= J1; j++) b2[j - 1] = 0.0;
+			b2[2 - 1] = -SO(i, 2, KS);
+			b2[J1 - 1] = -SO(i, JJ, KS);
+			orc_dpttrs(J1 - 1, &SORT(2, i, 0), &SORT(3, i, 1), &b2[1]);
+			real_t alpha = b2[2 - 1] + b2[J1 - 1];
+			real_t beta = b[2 - 1] + b[J1 - 1];
+			beta = beta / (1.0 + alpha);
+			for (int j = 2; j <= J1; j++) Q(i, j) = b[j - 1] - beta * b2[j - 1];
+		}
+		wrap_y(q, II, JJ);
+		if (PER_X(ipn)) wrap_x(q, II, JJ);
+	}
+}
+#undef SO
+#undef Q
+#undef QF
+#undef SORT

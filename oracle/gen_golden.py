@@ -44,7 +44,7 @@ class RefML:
         the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)"""
         self.R, self.relax, self.pre, self.post, self.cycle = R, relax, nrelax_pre, nrelax_post, cycle
         self.ibc = ibc
-        assert ibc == 0 or (so.ndim == 3 and relax == "point")
+        assert ibc == 0 or so.ndim == 3
         self.nd = nd = so.ndim - 1
         n = [s - 2 for s in so.shape[1:]][::-1]  # nx, ny[, nz]
         ng = 0
@@ -69,7 +69,15 @@ class RefML:
             if nd == 2 and ibc:
                 R.setup_interp2(F, Pm, ibc=ibc)
                 R.galerkin2(F, K, Pm, ibc=ibc)
-                R.setup_recip2(F, self.SOR[l][0])
+                if relax == "point":
+                    R.setup_recip2(F, self.SOR[l][0])
+                elif relax == "line-x":
+                    R.setup_lines2(F, self.SOR[l][0], "x", ibc=ibc)
+                elif relax == "line-y":
+                    R.setup_lines2(F, self.SOR[l][0], "y", ibc=ibc)
+                else:
+                    R.setup_lines2(F, self.SOR[l][0], "x", ibc=ibc)
+                    R.setup_lines2(F, self.SOR[l][1], "y", ibc=ibc)
             elif nd == 2:
                 R.setup_interp2(F, Pm)
                 R.galerkin2(F, K, Pm)
@@ -103,8 +111,20 @@ class RefML:
         for _ in range(n):
             if self.nd == 3:
                 R.relax3(A, b, x, S[0], ud)
-            elif self.ibc:
+            elif self.ibc and self.relax == "point":
                 R.relax2(A, b, x, S[0], ud, ibc=self.ibc)
+            elif self.ibc:
+                kw = dict(ibc=self.ibc)
+                if self.relax == "line-x":
+                    R.relax_lines2(A, b, x, S[0], ud, "x", **kw)
+                elif self.relax == "line-y":
+                    R.relax_lines2(A, b, x, S[0], ud, "y", **kw)
+                elif ud == DOWN:
+                    R.relax_lines2(A, b, x, S[0], ud, "x", **kw)
+                    R.relax_lines2(A, b, x, S[1], ud, "y", **kw)
+                else:
+                    R.relax_lines2(A, b, x, S[1], ud, "y", **kw)
+                    R.relax_lines2(A, b, x, S[0], ud, "x", **kw)
             elif self.relax == "point":
                 R.relax2(A, b, x, S[0], ud)
             elif self.relax == "line-x":

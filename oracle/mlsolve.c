@@ -83,7 +83,7 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
                          int relax, int nrelax_pre, int nrelax_post, int min_coarse,
                          int num_levels, int ibc)
 {
-	if (ibc != 0 && (nd != 2 || relax != ORC_RELAX_POINT)) return NULL;
+	if (ibc != 0 && nd != 2) return NULL;
 	orc_ml *ml = (orc_ml *)calloc(1, sizeof(orc_ml));
 	ml->ibc = ibc;
 	ml->nd = nd; ml->relax = relax;
@@ -116,7 +116,14 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
 		if (nd == 2 && ibc) {
 			orc2_setup_interp_per(F->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd, ibc);
 			orc2_galerkin_per(F->A, K->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd, ibc);
-			orc2_setup_recip(F->A, F->SOR0, F->II, F->JJ);
+			switch (relax) {
+			case ORC_RELAX_POINT: orc2_setup_recip(F->A, F->SOR0, F->II, F->JJ); break;
+			case ORC_RELAX_LINE_X: orc2_setup_lines_x_per(F->A, F->SOR0, F->II, F->JJ, ibc); break;
+			case ORC_RELAX_LINE_Y: orc2_setup_lines_y_per(F->A, F->SOR0, F->II, F->JJ, ibc); break;
+			default:
+				orc2_setup_lines_x_per(F->A, F->SOR0, F->II, F->JJ, ibc);
+				orc2_setup_lines_y_per(F->A, F->SOR1, F->II, F->JJ, ibc);
+			}
 		} else if (nd == 2) {
 			orc2_setup_interp(F->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd);
 			orc2_galerkin(F->A, K->A, K->P, F->II, F->JJ, K->II, K->JJ, ifd);
@@ -186,8 +193,20 @@ static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, i
 			continue;
 		}
 		int ifd = L->nst == 3;
-		if (ml->ibc) {
-			orc2_relax_gs_per(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown, ml->ibc);
+		if (ml->ibc) { /* L->res doubles as the line scratch, as in the non-periodic y-line call below */
+			switch (ml->relax) {
+			case ORC_RELAX_POINT: orc2_relax_gs_per(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown, ml->ibc); break;
+			case ORC_RELAX_LINE_X: orc2_relax_lines_x_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc); break;
+			case ORC_RELAX_LINE_Y: orc2_relax_lines_y_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc); break;
+			default:
+				if (updown == BMG_DOWN) {
+					orc2_relax_lines_x_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
+					orc2_relax_lines_y_per(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
+				} else {
+					orc2_relax_lines_y_per(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
+					orc2_relax_lines_x_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
+				}
+			}
 			continue;
 		}
 		switch (ml->relax) {

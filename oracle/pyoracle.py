@@ -57,13 +57,22 @@ class Oracle:
         else:
             self.L.orc2_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
 
-    def setup_lines2(self, so, sor, d):
+    def setup_lines2(self, so, sor, d, ibc=0):
         _, JJ, II = so.shape
+        if ibc:
+            f = self.L.orc2_setup_lines_x_per if d == "x" else self.L.orc2_setup_lines_y_per
+            f(_p(so), _p(sor), u(II), u(JJ), ibc)
+            return
         f = self.L.orc2_setup_lines_x if d == "x" else self.L.orc2_setup_lines_y
         f(_p(so), _p(sor), u(II), u(JJ))
 
-    def relax_lines2(self, so, qf, q, sor, updown, d):
+    def relax_lines2(self, so, qf, q, sor, updown, d, ibc=0):
         nst, JJ, II = so.shape
+        if ibc:
+            b = np.zeros(2 * JJ + II)
+            f = self.L.orc2_relax_lines_x_per if d == "x" else self.L.orc2_relax_lines_y_per
+            f(_p(so), _p(qf), _p(q), _p(sor), _p(b), u(II), u(JJ), int(nst == 3), updown, ibc)
+            return
         if d == "x":
             self.L.orc2_relax_lines_x(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
         else:
@@ -212,7 +221,7 @@ class Oracle:
         h = self.L.orc_ml_create_bc(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
                                     nrelax_pre, nrelax_post, min_coarse, num_levels, ibc)
         if not h:
-            raise ValueError("periodic boundary conditions: 2D point relaxation only")
+            raise ValueError("periodic boundary conditions: 2D only")
         m = MLHandle(self, h, nd)
         if cycle == "f":
             self.L.orc_ml_set_cycle(m.h, 1)
@@ -274,16 +283,16 @@ class Ref:
         nst, JJ, II = so.shape
         self.L.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, ibc)
 
-    def setup_lines2(self, so, sor, d):
+    def setup_lines2(self, so, sor, d, ibc=0):
         nst, JJ, II = so.shape
         f = self.L.BMG2_SymStd_SETUP_lines_x if d == "x" else self.L.BMG2_SymStd_SETUP_lines_y
-        f(_p(so), _p(sor), u(II), u(JJ), nst, 0)
+        f(_p(so), _p(sor), u(II), u(JJ), nst, ibc)
 
-    def relax_lines2(self, so, qf, q, sor, updown, d):
+    def relax_lines2(self, so, qf, q, sor, updown, d, ibc=0):
         nst, JJ, II = so.shape
-        b = np.zeros(2 * JJ + II)
+        b = np.zeros(2 * JJ + 2 * II)
         f = self.L.BMG2_SymStd_relax_lines_x if d == "x" else self.L.BMG2_SymStd_relax_lines_y
-        f(1, _p(so), _p(qf), _p(q), _p(sor), _p(b), u(II), u(JJ), 1, int(nst == 3), nst, 1, updown, 0)
+        f(1, _p(so), _p(qf), _p(q), _p(sor), _p(b), u(II), u(JJ), 1, int(nst == 3), nst, 1, updown, ibc)
 
     def residual2(self, so, qf, q, res):
         nst, JJ, II = so.shape

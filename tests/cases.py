@@ -230,6 +230,16 @@ def kernel_suite_per(impl, case):
     x, xc, res = pb.uniform(g, sd + 4, -1, 1), pb.uniform(gc, sd + 5, -1, 1), pb.uniform(g, sd + 6, -1, 1)
     impl.interp_add2(x, xc, res, so, ci, ibc=ibc)
     out["interp_add_q"], out["interp_add_res"] = x.copy(), res.copy()
+    # line relaxation: cyclic tridiagonals (Sherman-Morrison) in the wrapped direction
+    q0 = pb.uniform(g, sd + 7, -1, 1)
+    for d in "xy":
+        sl = np.zeros((2,) + g)
+        impl.setup_lines2(so, sl, d, ibc=ibc)
+        out[f"setup_lines_{d}"] = sl.copy()
+        q = q0.copy()
+        for ud in (DOWN, UP):
+            impl.relax_lines2(so, qf, q, sl, ud, d, ibc=ibc)
+            out[f"relax_lines_{d}{ud}"] = q.copy()
     return out
 
 
@@ -268,4 +278,17 @@ SOLVES_PER = {
     "perrand5_xy_64_v21": (lambda: pb.periodic_random_op(64, 64, 3, (True, True), 7),
                            lambda: pb.periodic_rhs2(64, 64, (True, True)),
                            dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=3)),
+    # line relaxation on periodic problems
+    "perpoisson5_x_200x60_linex": (lambda: pb.periodic_poisson2(200, 60, (True, False)),
+                                   lambda: pb.periodic_rhs2(200, 60, (True, False)),
+                                   dict(relax="line-x", nrelax_pre=2, nrelax_post=1, ibc=2)),
+    "perpoisson5_y_60x200_liney": (lambda: pb.periodic_poisson2(60, 200, (False, True)),
+                                   lambda: pb.periodic_rhs2(60, 200, (False, True)),
+                                   dict(relax="line-y", nrelax_pre=2, nrelax_post=1, ibc=1)),
+    "perrand9_xy_96x80_linexy": (lambda: pb.periodic_random_op(96, 80, 5, (True, True), 5),
+                                 lambda: pb.periodic_rhs2(96, 80, (True, True)),
+                                 dict(relax="line-xy", nrelax_pre=2, nrelax_post=1, ibc=3)),
+    "perrand9_x_100x75_linexy": (lambda: pb.periodic_random_op(100, 75, 5, (True, False), 6),
+                                 lambda: pb.periodic_rhs2(100, 75, (True, False)),
+                                 dict(relax="line-xy", nrelax_pre=2, nrelax_post=1, ibc=2)),
 }
