@@ -28,6 +28,7 @@ struct orc_ml {
 	int ibc;              /* 0 Dirichlet; 2D only: 1 per_y, 2 per_x, 3 per_xy (BMG_get_bc.f90:13-16) */
 	orc_level *lv;
 	real_t *ABD, *bbd;
+	real_t *work;         /* line-relaxation scratch B (2*(II+JJ) of level 0), separate as in the reference */
 	len_t nabd1, nabd2;
 };
 
@@ -108,6 +109,7 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
 	else { ml->nabd1 = C->nx * (C->ny + 1) + 2; ml->nabd2 = C->nx * C->ny * C->nz; }
 	ml->ABD = zalloc((size_t)ml->nabd1 * ml->nabd2);
 	ml->bbd = zalloc(ml->nabd2);
+	ml->work = zalloc(2 * ((size_t)ml->lv[0].II + ml->lv[0].JJ) + 8);
 
 	/* setup loop: interp -> operator -> relax for l = 0 .. nlev-2 */
 	for (int l = 0; l < nlev - 1; l++) {
@@ -156,7 +158,7 @@ void orc_ml_destroy(orc_ml *ml)
 		free(L->A); free(L->P); free(L->res); free(L->SOR0); free(L->SOR1);
 		if (l > 0) { free(L->x); free(L->b); }
 	}
-	free(ml->lv); free(ml->ABD); free(ml->bbd); free(ml);
+	free(ml->lv); free(ml->ABD); free(ml->bbd); free(ml->work); free(ml);
 }
 
 int orc_ml_nlevels(const orc_ml *ml) { return ml->nlev; }
@@ -196,15 +198,15 @@ static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, i
 		if (ml->ibc) { /* L->res doubles as the line scratch, as in the non-periodic y-line call below */
 			switch (ml->relax) {
 			case ORC_RELAX_POINT: orc2_relax_gs_per(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown, ml->ibc); break;
-			case ORC_RELAX_LINE_X: orc2_relax_lines_x_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc); break;
-			case ORC_RELAX_LINE_Y: orc2_relax_lines_y_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc); break;
+			case ORC_RELAX_LINE_X: orc2_relax_lines_x_per(L->A, b, x, L->SOR0, ml->work, L->II, L->JJ, ifd, updown, ml->ibc); break;
+			case ORC_RELAX_LINE_Y: orc2_relax_lines_y_per(L->A, b, x, L->SOR0, ml->work, L->II, L->JJ, ifd, updown, ml->ibc); break;
 			default:
 				if (updown == BMG_DOWN) {
-					orc2_relax_lines_x_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
-					orc2_relax_lines_y_per(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
+					orc2_relax_lines_x_per(L->A, b, x, L->SOR0, ml->work, L->II, L->JJ, ifd, updown, ml->ibc);
+					orc2_relax_lines_y_per(L->A, b, x, L->SOR1, ml->work, L->II, L->JJ, ifd, updown, ml->ibc);
 				} else {
-					orc2_relax_lines_y_per(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
-					orc2_relax_lines_x_per(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown, ml->ibc);
+					orc2_relax_lines_y_per(L->A, b, x, L->SOR1, ml->work, L->II, L->JJ, ifd, updown, ml->ibc);
+					orc2_relax_lines_x_per(L->A, b, x, L->SOR0, ml->work, L->II, L->JJ, ifd, updown, ml->ibc);
 				}
 			}
 			continue;
@@ -212,13 +214,13 @@ static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, i
 		switch (ml->relax) {
 		case ORC_RELAX_POINT: orc2_relax_gs(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown); break;
 		case ORC_RELAX_LINE_X: orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown); break;
-		case ORC_RELAX_LINE_Y: orc2_relax_lines_y(L->A, b, x, L->SOR0, L->res, L->II, L->JJ, ifd, updown); break;
+		case ORC_RELAX_LINE_Y: orc2_relax_lines_y(L->A, b, x, L->SOR0, ml->work, L->II, L->JJ, ifd, updown); break;
 		default:
 			if (updown == BMG_DOWN) {
 				orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown);
-				orc2_relax_lines_y(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown);
+				orc2_relax_lines_y(L->A, b, x, L->SOR1, ml->work, L->II, L->JJ, ifd, updown);
 			} else {
-				orc2_relax_lines_y(L->A, b, x, L->SOR1, L->res, L->II, L->JJ, ifd, updown);
+				orc2_relax_lines_y(L->A, b, x, L->SOR1, ml->work, L->II, L->JJ, ifd, updown);
 				orc2_relax_lines_x(L->A, b, x, L->SOR0, L->II, L->JJ, ifd, updown);
 			}
 		}
