@@ -144,15 +144,15 @@ class Kernels:
         nst, JJ, II = so.shape
         lib.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, ibc)
 
-    def setup_lines2(self, so, sor, d):
+    def setup_lines2(self, so, sor, d, ibc=0):
         nst, JJ, II = so.shape
         f = lib.BMG2_SymStd_SETUP_lines_x if d == "x" else lib.BMG2_SymStd_SETUP_lines_y
-        f(_p(so), _p(sor), u(II), u(JJ), nst, 0)
+        f(_p(so), _p(sor), u(II), u(JJ), nst, ibc)
 
-    def relax_lines2(self, so, qf, q, sor, updown, d):
+    def relax_lines2(self, so, qf, q, sor, updown, d, ibc=0):
         nst, JJ, II = so.shape
         f = lib.BMG2_SymStd_relax_lines_x if d == "x" else lib.BMG2_SymStd_relax_lines_y
-        f(1, _p(so), _p(qf), _p(q), _p(sor), None, u(II), u(JJ), 1, int(nst == 3), nst, 1, updown, 0)
+        f(1, _p(so), _p(qf), _p(q), _p(sor), None, u(II), u(JJ), 1, int(nst == 3), nst, 1, updown, ibc)
 
     def residual2(self, so, qf, q, res):
         nst, JJ, II = so.shape

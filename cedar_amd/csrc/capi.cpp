@@ -238,18 +238,20 @@ void BMG2_SymStd_residual(int *k, real_t *SO, real_t *QF, real_t *Q, real_t *RES
 
 void BMG2_SymStd_SETUP_lines_x(real_t *SO, real_t *SOR, len_t Nx, len_t Ny, int NStncl, int JPN)
 {
-	if (!dirichlet(JPN, "BMG2_SymStd_SETUP_lines_x")) return;
+	const int ipn = bc2(JPN, "BMG2_SymStd_SETUP_lines_x");
+	if (ipn < 0) return;
 	size_t P = (size_t)Nx * Ny;
 	Staged sso(SO, P * NStncl, true, false), ssor(SOR, P * 2, true, true);
-	setup_lines_x(sso.get(), ssor.get(), (int)Nx, (int)Ny, current_stream());
+	setup_lines_x(sso.get(), ssor.get(), (int)Nx, (int)Ny, current_stream(), ipn == 2 || ipn == 3);
 }
 
 void BMG2_SymStd_SETUP_lines_y(real_t *SO, real_t *SOR, len_t Nx, len_t Ny, int NStncl, int JPN)
 {
-	if (!dirichlet(JPN, "BMG2_SymStd_SETUP_lines_y")) return;
+	const int ipn = bc2(JPN, "BMG2_SymStd_SETUP_lines_y");
+	if (ipn < 0) return;
 	size_t P = (size_t)Nx * Ny;
 	Staged sso(SO, P * NStncl, true, false), ssor(SOR, P * 2, true, true);
-	setup_lines_y(sso.get(), ssor.get(), (int)Nx, (int)Ny, current_stream());
+	setup_lines_y(sso.get(), ssor.get(), (int)Nx, (int)Ny, current_stream(), ipn == 1 || ipn == 3);
 }
 
 void BMG2_SymStd_relax_lines_x(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, real_t *B,
@@ -257,13 +259,14 @@ void BMG2_SymStd_relax_lines_x(int k, real_t *SO, real_t *QF, real_t *Q, real_t 
                                int updown, int jpn)
 {
 	(void)B;
-	if (!dirichlet(jpn, "BMG2_SymStd_relax_lines_x")) return;
+	const int ipn = bc2(jpn, "BMG2_SymStd_relax_lines_x");
+	if (ipn < 0) return;
 	size_t P = (size_t)II * JJ;
 	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
 	if (nst_eff > nstencil) nst_eff = nstencil;
 	int ud = (irelax_sym == 0) ? BMG_DOWN : updown;
 	Staged sso(SO, P * nstencil, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
-	relax_lines_x(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream());
+	relax_lines_x(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)II, (int)JJ, nst_eff, ud, current_stream(), ipn);
 }
 
 void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t *SOR, real_t *B,
@@ -271,7 +274,8 @@ void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t 
                                int updown, int jpn)
 {
 	(void)B; // the reference's 2*JJ per-line scratch is too small for a whole colour: own HBM scratch
-	if (!dirichlet(jpn, "BMG2_SymStd_relax_lines_y")) return;
+	const int ipn = bc2(jpn, "BMG2_SymStd_relax_lines_y");
+	if (ipn < 0) return;
 	size_t P = (size_t)II * JJ;
 	int nst_eff = (k < kf || ifd != 1) ? 5 : 3;
 	if (nst_eff > nstencil) nst_eff = nstencil;
@@ -280,7 +284,7 @@ void BMG2_SymStd_relax_lines_y(int k, real_t *SO, real_t *QF, real_t *Q, real_t 
 	real_t *scr = static_cast<real_t *>(pool_get(nscr * sizeof(real_t)));
 	{
 		Staged sso(SO, P * nstencil, true, false), sqf(QF, P, true, false), sq(Q, P, true, true), ssor(SOR, P * 2, true, false);
-		relax_lines_y(sso.get(), sqf.get(), sq.get(), ssor.get(), scr, (int)II, (int)JJ, nst_eff, ud, current_stream());
+		relax_lines_y(sso.get(), sqf.get(), sq.get(), ssor.get(), scr, (int)II, (int)JJ, nst_eff, ud, current_stream(), ipn);
 	}
 	CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream()));
 	pool_put(scr, nscr * sizeof(real_t));

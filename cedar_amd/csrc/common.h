@@ -105,14 +105,14 @@ void galerkin2(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF
 void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                int IIC, int JJC, int KKC, int ifd, hipStream_t st);
 // lines.hip
-void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st);
-void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st);
+void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
+void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st);
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0);
 // scratch: line-contiguous buffer of ylines_scratch_doubles(II,JJ) doubles in HBM
 size_t ylines_scratch_doubles(int II, int JJ);
 void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *scratch,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st);
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0);
 // cgsolve.hip
 void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
 void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);

@@ -65,19 +65,42 @@ __global__ void lines_factor(real_t *__restrict__ sor, int n /*unknowns*/, int l
 	}
 }
 
-void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st)
+// periodic lines: the wrap-around coupling is folded into the two end diagonals before the
+// factorisation (SETUP_lines_x.f90:76-83, SETUP_lines_y.f90:78-85); the solves undo it with a
+// Sherman-Morrison correction (relax_lines_x.f90:209-226)
+__global__ void lines_fold_x(const real_t *__restrict__ so, real_t *__restrict__ sor, int II, int JJ)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x + 1; // 0-based interior row
+	if (j > JJ - 2) return;
+	const size_t PS = (size_t)II * JJ, r = (size_t)II * j;
+	sor[r + 1] = sor[r + 1] + so[KW * PS + r + 1];
+	sor[r + II - 2] = sor[r + II - 2] + so[KW * PS + r + II - 1];
+}
+
+__global__ void lines_fold_y(const real_t *__restrict__ so, real_t *__restrict__ sor, int II, int JJ)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+	if (i > II - 2) return;
+	const size_t PS = (size_t)II * JJ, c = (size_t)JJ * i; // SOR(JJ,II,2): column i
+	sor[c + 1] = sor[c + 1] + so[KS * PS + (size_t)i + (size_t)II];
+	sor[c + JJ - 2] = sor[c + JJ - 2] + so[KS * PS + (size_t)i + (size_t)II * (JJ - 1)];
+}
+
+void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold)
 {
 	if (II < 3 || JJ < 3) return;
 	dim3 grid((II - 2 + 255) / 256, JJ - 2);
 	hipLaunchKernelGGL(lines_fill_x, grid, dim3(256), 0, st, so, sor, II, JJ);
+	if (fold) hipLaunchKernelGGL(lines_fold_x, dim3((JJ - 2 + 63) / 64), dim3(64), 0, st, so, sor, II, JJ);
 	hipLaunchKernelGGL(lines_factor, dim3((JJ - 2 + 63) / 64), dim3(64), 0, st, sor, II - 2, II, JJ - 2, (size_t)II * JJ);
 }
 
-void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st)
+void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold)
 {
 	if (II < 3 || JJ < 3) return;
 	dim3 grid((II - 2 + 255) / 256, JJ - 2);
 	hipLaunchKernelGGL(lines_fill_y, grid, dim3(256), 0, st, so, sor, II, JJ);
+	if (fold) hipLaunchKernelGGL(lines_fold_y, dim3((II - 2 + 63) / 64), dim3(64), 0, st, so, sor, II, JJ);
 	hipLaunchKernelGGL(lines_factor, dim3((II - 2 + 63) / 64), dim3(64), 0, st, sor, JJ - 2, JJ, II - 2, (size_t)II * JJ);
 }
 
@@ -181,7 +204,33 @@ __device__ __forceinline__ void line_pttrs(real_t *y, int n, const real_t *__res
 static inline size_t line_lds_doubles(int n) { return (size_t)n + (size_t)(n >> 3) + 24; }
 
 // ------------------------------------------------------------------ x-lines
-template <int BS, bool NINE>
+// Sherman-Morrison closure of a cyclic line held in LDS: y holds the solution of the folded system;
+// a second solve with the rank-one column u (-c_first at the first, -c_last at the last unknown),
+// alpha = u_1 + u_n, beta = (y_1 + y_n) / (1 + alpha), x = y - beta u (relax_lines_x.f90:212-226).
+// On return `y` holds u and every lane holds beta; ys[t] (lane-strided) kept the first solution.
+template <int BS>
+__device__ __forceinline__ real_t line_sherman_morrison(real_t *y, int n, const real_t *__restrict__ d,
+                                                        const real_t *__restrict__ e, real_t cfirst, real_t clast,
+                                                        real_t *wa, real_t *wc, real_t *cs, real_t &y1, real_t &yn)
+{
+	y1 = y[lpad(0)];
+	yn = y[lpad(n - 1)];
+	__syncthreads();
+	for (int t = threadIdx.x; t < n; t += BS) y[lpad(t)] = 0.0;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		y[lpad(0)] = -cfirst;
+		y[lpad(n - 1)] = -clast; // n == 1: the second assignment wins, as in the reference
+	}
+	__syncthreads();
+	line_pttrs<BS>(y, n, d, e, wa, wc, cs);
+	const real_t alpha = y[lpad(0)] + y[lpad(n - 1)];
+	real_t beta = y1 + yn;
+	beta = beta / (1.0 + alpha);
+	return beta;
+}
+
+template <int BS, bool NINE, bool SM = false>
 __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                             real_t *__restrict__ q, const real_t *__restrict__ sor,
                                                             int II, int JJ, int jb, int nlines)
@@ -211,6 +260,12 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 	__syncthreads();
 	line_pttrs<BS>(y, n, sor + row + 1, sor + PS + row + 2, wa, wc, cs);
 	for (int t = threadIdx.x; t < n; t += BS) q[row + 1 + t] = y[lpad(t)];
+	if (SM) {
+		real_t y1, yn;
+		const real_t beta = line_sherman_morrison<BS>(y, n, sor + row + 1, sor + PS + row + 2, so[KW * PS + row + 1],
+		                                              so[KW * PS + row + II - 1], wa, wc, cs, y1, yn);
+		for (int t = threadIdx.x; t < n; t += BS) q[row + 1 + t] = q[row + 1 + t] - beta * y[lpad(t)]; // same lane wrote it
+	}
 }
 
 static bool lds_ok(int n, const char *who)
@@ -222,35 +277,47 @@ static bool lds_ok(int n, const char *who)
 	return true;
 }
 
+template <int BS, bool NINE, bool SM>
+static void launch_x_k(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, int nlines,
+                       hipStream_t st)
+{
+	size_t shm = line_lds_doubles(II - 2) * sizeof(real_t);
+	auto k = relax_lines_x_kernel<BS, NINE, SM>;
+	if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+	hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines);
+}
+
 template <int BS>
 static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                     int nstncl, int jb, hipStream_t st)
+                     int nstncl, int jb, hipStream_t st, bool sm = false)
 {
 	int nlines = (JJ - 2 - jb + 1) / 2;
 	if (nlines <= 0) return;
-	size_t shm = line_lds_doubles(II - 2) * sizeof(real_t);
 	if (nstncl == 5) {
-		auto k = relax_lines_x_kernel<BS, true>;
-		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-		hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines);
+		if (sm) launch_x_k<BS, true, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
+		else launch_x_k<BS, true, false>(so, qf, q, sor, II, JJ, jb, nlines, st);
 	} else {
-		auto k = relax_lines_x_kernel<BS, false>;
-		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-		hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines);
+		if (sm) launch_x_k<BS, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
+		else launch_x_k<BS, false, false>(so, qf, q, sor, II, JJ, jb, nlines, st);
 	}
 }
 
+// ipn: 0 Dirichlet; 1 periodic in y only: ordinary solves, one y wrap after the sweep (relax_lines_x.f90:75-176);
+// 2 / 3 periodic in x (/ and y): cyclic lines, y then x wrap after each colour (:178-300)
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st)
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn)
 {
 	if (II < 3 || JJ < 3) return;
 	lds_ok(II - 2, "relax_lines_x");
+	const bool sm = ipn == 2 || ipn == 3;
 	for (int c = 0; c < 2; c++) {
 		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
 		int jb = (updown == BMG_DOWN) ? 1 - c : c;
-		if (II - 2 <= 512) launch_x<64>(so, qf, q, sor, II, JJ, nstncl, jb, st);
-		else launch_x<256>(so, qf, q, sor, II, JJ, nstncl, jb, st);
+		if (II - 2 <= 512) launch_x<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm);
+		else launch_x<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm);
+		if (sm) wrap2(q, II, JJ, 1, ipn == 3, 1, st);
 	}
+	if (ipn == 1) wrap2(q, II, JJ, 1, 1, 0, st);
 }
 
 // ------------------------------------------------------------------ y-lines
@@ -289,9 +356,10 @@ __global__ __launch_bounds__(256) void ylines_rhs_T(const real_t *__restrict__ s
 	}
 }
 
-template <int BS>
+template <int BS, bool SM = false>
 __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, const real_t *__restrict__ sor,
-                                                    int II, int JJ, int ib, int nlines, int ldt)
+                                                    int II, int JJ, int ib, int nlines, int ldt,
+                                                    const real_t *__restrict__ so = nullptr)
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int n = JJ - 2;
@@ -307,6 +375,13 @@ __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, cons
 	// SOR(JJ,II,2): d = SOR(2.., i) , e = SOR(3.., i, 2)
 	line_pttrs<BS>(y, n, sor + (size_t)JJ * i + 1, sor + PS + (size_t)JJ * i + 2, wa, wc, cs);
 	for (int t = threadIdx.x; t < n; t += BS) line[t] = y[lpad(t)];
+	if (SM) { // relax_lines_y.f90:196-207: u = -SO(I,2,KS) e_first - SO(I,JJ,KS) e_last
+		real_t y1, yn;
+		const real_t beta = line_sherman_morrison<BS>(y, n, sor + (size_t)JJ * i + 1, sor + PS + (size_t)JJ * i + 2,
+		                                              so[KS * PS + (size_t)i + (size_t)II], so[KS * PS + (size_t)i + (size_t)II * (JJ - 1)],
+		                                              wa, wc, cs, y1, yn);
+		for (int t = threadIdx.x; t < n; t += BS) line[t] = line[t] - beta * y[lpad(t)];
+	}
 }
 
 __global__ __launch_bounds__(256) void ylines_scatter_T(const real_t *__restrict__ bt, real_t *__restrict__ q,
@@ -332,9 +407,12 @@ size_t ylines_scratch_doubles(int II, int JJ)
 	return (size_t)((II - 2 + 1) / 2) * (size_t)((n + 15) & ~15) + 16;
 }
 
+// ipn: 0 Dirichlet; 2 periodic in x only: ordinary solves, one x wrap after the sweep (relax_lines_y.f90:77-176);
+// 1 / 3 periodic in y (/ and x): cyclic lines, y then x wrap after each colour (:178-300)
 void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *bt,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st)
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn)
 {
+	const bool sm = ipn == 1 || ipn == 3;
 	if (II < 3 || JJ < 3) return;
 	lds_ok(JJ - 2, "relax_lines_y");
 	const int n = JJ - 2;
@@ -350,14 +428,21 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 		else
 			hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
 		if (n <= 512) {
-			hipLaunchKernelGGL(ylines_solve<64>, dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt);
-		} else {
-			auto k = ylines_solve<256>;
+			if (sm) hipLaunchKernelGGL((ylines_solve<64, true>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
+			else hipLaunchKernelGGL((ylines_solve<64, false>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
+		} else if (sm) {
+			auto k = ylines_solve<256, true>;
 			if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-			hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt);
+			hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
+		} else {
+			auto k = ylines_solve<256, false>;
+			if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+			hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
 		}
 		hipLaunchKernelGGL(ylines_scatter_T, tg, dim3(256), 0, st, bt, q, II, JJ, ib, nlines, ldt);
+		if (sm) wrap2(q, II, JJ, 1, 1, ipn == 3, st);
 	}
+	if (ipn == 2) wrap2(q, II, JJ, 1, 0, 1, st);
 }
 
 } // namespace cedar_amd

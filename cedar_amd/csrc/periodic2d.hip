@@ -1,5 +1,5 @@
-// 2D periodic boundary conditions (ibc = 1 per_y, 2 per_x, 3 per_xy; BMG_get_bc.f90:13-16), point
-// relaxation.  Replaces the periodic branches of
+// 2D periodic boundary conditions (ibc = 1 per_y, 2 per_x, 3 per_xy; BMG_get_bc.f90:13-16): point
+// relaxation, transfers, set-up and the coarsest solve.  Replaces the periodic branches of
 //   BMG2_SymStd_relax_GS          (src/2d/ftn/BMG2_SymStd_relax_GS.f90:139-226)
 //   BMG2_SymStd_restrict          (..._restrict.f90:94-128)          ghost refresh, then restrict
 //   BMG2_SymStd_interp_add        (..._interp_add.f90:139-156)       interp_add, then ghost wraps
@@ -8,7 +8,7 @@
 //   BMG2_SymStd_SETUP_cg_LU       (..._SETUP_cg_LU.f90:148-218, :262-330)    dense matrix + DPOTRF
 //   BMG2_SymStd_SOLVE_cg          (..._SOLVE_cg.f90:95-163)          DPOTRS, mean removal, wraps
 // Same operation order as the reference => relax / restrict / interp_add / interpolation bit-identical.
-// Periodic line relaxation (cyclic tridiagonals) is not implemented; callers are refused loudly.
+// Periodic line relaxation (cyclic tridiagonals, Sherman-Morrison) lives in lines.hip.
 #include "common.h"
 #include <cfloat>
 

@@ -113,21 +113,22 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 			relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
 			continue;
 		}
-		if (s->st.ibc) { // periodic branch (point relaxation; enforced at create)
-			relax2_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, s->st.ibc, st);
+		const int ipn = s->st.ibc;
+		if (ipn && s->st.relaxation == CEDAR_AMD_RELAX_POINT) { // periodic point relaxation
+			relax2_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, ipn, st);
 			continue;
 		}
 		switch (s->st.relaxation) {
 		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
-		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
-		case CEDAR_AMD_RELAX_LINE_Y: relax_lines_y(L.A, b, x, L.SOR0, L.yscr, L.II, L.JJ, L.nst, updown, st); break;
+		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn); break;
+		case CEDAR_AMD_RELAX_LINE_Y: relax_lines_y(L.A, b, x, L.SOR0, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn); break;
 		default:
 			if (updown == BMG_DOWN) {
-				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st);
-				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn);
+				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn);
 			} else {
-				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st);
-				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st);
+				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn);
 			}
 		}
 	}
@@ -253,12 +254,12 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		s->st.relaxation = CEDAR_AMD_RELAX_POINT;
 	}
 	if (s->st.ibc != 0) {
-		// periodic boundary conditions: 2D, point relaxation, V-cycle, rows that fit the LDS window
-		const bool ok = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3 && s->st.relaxation == CEDAR_AMD_RELAX_POINT
-		                && s->st.cycle == 0 && (size_t)(nx + 2) * sizeof(real_t) <= 64 * 1024;
+		// periodic boundary conditions: 2D, V-cycle; point relaxation keeps a row in the default LDS window
+		const bool ok = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3 && s->st.cycle == 0
+		                && (s->st.relaxation != CEDAR_AMD_RELAX_POINT || (size_t)(nx + 2) * sizeof(real_t) <= 64 * 1024);
 		if (!ok) {
-			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for 2D point relaxation "
-			             "V-cycles (ibc 1..3, rows up to 8190 points); no solver created";
+			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for 2D V-cycles "
+			             "(ibc 1..3; point relaxation: rows up to 8190 points); no solver created";
 			print_error(msg);
 			delete s;
 			return nullptr;
@@ -314,11 +315,11 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 			}
 			switch (s->st.relaxation) {
 			case CEDAR_AMD_RELAX_POINT: setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, 1, st); break;
-			case CEDAR_AMD_RELAX_LINE_X: setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st); break;
-			case CEDAR_AMD_RELAX_LINE_Y: setup_lines_y(F.A, F.SOR0, F.II, F.JJ, st); break;
+			case CEDAR_AMD_RELAX_LINE_X: setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st, s->st.ibc == 2 || s->st.ibc == 3); break;
+			case CEDAR_AMD_RELAX_LINE_Y: setup_lines_y(F.A, F.SOR0, F.II, F.JJ, st, s->st.ibc == 1 || s->st.ibc == 3); break;
 			default:
-				setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st);
-				setup_lines_y(F.A, F.SOR1, F.II, F.JJ, st);
+				setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st, s->st.ibc == 2 || s->st.ibc == 3);
+				setup_lines_y(F.A, F.SOR1, F.II, F.JJ, st, s->st.ibc == 1 || s->st.ibc == 3);
 			}
 		} else {
 			int ifd = F.nst == 4;

@@ -186,7 +186,7 @@ typedef struct {
 	int min_coarse;   /* solver.min_coarse (3) :43 */
 	int cycle;        /* solver.cycle.type: 0 = "v" (default), 1 = "f" (include/cedar/cycle/fcycle.h:49-83) :30-36 */
 	int ibc;          /* boundary code of BMG_get_bc(per_mask) from grid.periodic (src/kernel_params.cc): 0 definite,
-	                     1 periodic in y, 2 in x, 3 in both (2D, point relaxation, V-cycle) */
+	                     1 periodic in y, 2 in x, 3 in both (2D, V-cycle) */
 } cedar_amd_settings;
 
 void cedar_amd_default_settings(cedar_amd_settings *s);

@@ -53,20 +53,6 @@ def test_periodic_kernels_vs_oracle(K, oracle, case):
             assert np.max(np.abs(got[k] - want[k])) <= 1e-13 * np.max(np.abs(want[k])), (case[0], k)
 
 
-def test_periodic_lines_and_3d_are_refused_loudly(K, capfd):
-    g = (10, 12)
-    so, q = pb.random_op(g, 5, 1), pb.uniform(g, 2)
-    q0 = q.copy()
-    sor = np.zeros((2,) + g)
-    K.setup_lines2(so, sor, "x")
-    from cedar_amd import capi
-    import ctypes as C
-    u = C.c_uint
-    capi.lib.BMG2_SymStd_relax_lines_x(1, capi._p(so), capi._p(q), capi._p(q), capi._p(sor), None, u(12), u(10), 1, 0, 5, 1, 0, 2)
-    assert np.array_equal(q, q0)
-    assert "only Dirichlet" in capfd.readouterr().err
-
-
 @pytest.mark.parametrize("name", list(cases.SOLVES_PER), ids=str)
 def test_periodic_solve_history_vs_reference_golden(name, oracle):
     """device-resident solver with ibc != 0 (hipGraph V-cycle): residual history of the reference's
@@ -81,7 +67,7 @@ def test_periodic_solve_history_vs_reference_golden(name, oracle):
     h = s.solve(b, x)
     want = [float(gold["res0_l2"])] + [float(v) for v in gold["rel_l2"]]
     assert len(h) == len(want)
-    np.testing.assert_allclose(h, want, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(h, want, rtol=1e-10, atol=1e-12 if "line" in name else 1e-14)
     inner = x[1:-1, 1:-1]
     assert abs(float(np.sqrt(np.cumsum((inner * inner).ravel())[-1])) - float(gold["x_l2"])) <= 1e-11 * float(gold["x_l2"])
     # hierarchy against the oracle: interpolation bit-exact, coarse operators to rounding
@@ -95,8 +81,18 @@ def test_periodic_solve_history_vs_reference_golden(name, oracle):
     s.close()
 
 
-def test_periodic_solver_refuses_lines(capfd):
+def test_periodic_solver_refuses_what_it_does_not_serve(capfd):
     from cedar_amd import capi
     with pytest.raises(RuntimeError):
-        capi.Solver(pb.periodic_poisson2(32, 32, (True, False)), relax="line-x", ibc=2)
-    assert "periodic boundary conditions are implemented for 2D point relaxation" in capfd.readouterr().err
+        capi.Solver(pb.periodic_poisson2(32, 32, (True, False)), cycle="f", ibc=2)
+    assert "periodic boundary conditions are implemented for 2D V-cycles" in capfd.readouterr().err
+
+
+def test_periodic_long_lines(K, oracle):
+    """cyclic lines longer than one scan tile (2048 unknowns) in both directions"""
+    for case in (("xl4500x6_9_x", 4500, 6, 5, 2), ("xl5x2300_9_y", 5, 2300, 5, 1), ("xl700x600_5_xy", 700, 600, 3, 3)):
+        got, want = cases.kernel_suite_per(K, case), cases.kernel_suite_per(oracle, case)
+        for k in want:
+            if k.startswith("relax_lines") or k.startswith("setup_lines"):
+                tol = 0.0 if k.startswith("setup") else 1e-11
+                assert np.max(np.abs(got[k] - want[k])) <= tol * np.max(np.abs(want[k])), (case[0], k)
