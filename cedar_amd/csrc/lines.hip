@@ -268,11 +268,16 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 	}
 }
 
+// a line must fit the 160 KB of LDS (up to ~18,000 unknowns); longer lines are refused through the
+// host's print_error callback like every other unsupported request, the sweep is skipped
+extern "C" void print_error(char *msg);
 static bool lds_ok(int n, const char *who)
 {
 	if (line_lds_doubles(n) * sizeof(real_t) > 160 * 1024 - 512) {
-		fprintf(stderr, "[cedar_amd] %s: line of %d unknowns does not fit the 160 KB LDS\n", who, n);
-		abort();
+		char buf[160];
+		snprintf(buf, sizeof(buf), "%s: a line of %d unknowns does not fit the 160 KB LDS of a CU; sweep skipped", who, n);
+		print_error(buf);
+		return false;
 	}
 	return true;
 }
@@ -308,7 +313,7 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
                    int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn)
 {
 	if (II < 3 || JJ < 3) return;
-	lds_ok(II - 2, "relax_lines_x");
+	if (!lds_ok(II - 2, "relax_lines_x")) return;
 	const bool sm = ipn == 2 || ipn == 3;
 	for (int c = 0; c < 2; c++) {
 		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
@@ -414,7 +419,7 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 {
 	const bool sm = ipn == 1 || ipn == 3;
 	if (II < 3 || JJ < 3) return;
-	lds_ok(JJ - 2, "relax_lines_y");
+	if (!lds_ok(JJ - 2, "relax_lines_y")) return;
 	const int n = JJ - 2;
 	const int ldt = (n + 15) & ~15;
 	const size_t shm = line_lds_doubles(n) * sizeof(real_t);
