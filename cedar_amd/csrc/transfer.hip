@@ -148,6 +148,60 @@ void interp_add2(real_t *q, const real_t *qc, real_t *res, const real_t *so, con
 }
 
 // ------------------------------------------------------------------ interp_add 3D
+// One workgroup per fine row (j,k), lane p owns the pair of 1-based columns (2p+2, 2p+3): an even
+// (coincides with / lies above a coarse column) and an odd one (between two coarse columns).  The
+// (j,k) parities are uniform over the row, so every lane runs the same two formulas: no divergence,
+// the fine arrays move as 16-byte pairs, the CI / coarse-q entries of a row as consecutive doubles.
+// Expressions and their evaluation order are those of BMG3_SymStd_interp_add.f90:88-240 (scatter in
+// the reference, gathered per fine point here); the written index ranges -- including the ghost
+// column / row / plane the reference touches for even extents -- are passed in by the host.
+template <bool KO, bool JO>
+__device__ __forceinline__ void interp_add3_pair(real_t &ve, real_t &vo, real_t re, real_t ro, bool upd_e, bool upd_o,
+                                                 const real_t *__restrict__ qc, const real_t *__restrict__ ci,
+                                                 size_t ce, size_t sc, size_t tc, size_t PC)
+{
+	const size_t co = ce + 1; // coarse column of the odd point: (i+1)/2+1
+#define CIe(slot) ci[(size_t)(slot)*PC + ce]
+#define CIo(slot) ci[(size_t)(slot)*PC + co]
+	if (!KO) {
+		if (!JO) {
+			if (upd_e) ve = ve + qc[ce];
+			if (upd_o) {
+				real_t a = CIo(LXYR) * qc[co] + CIo(LXYL) * qc[co - 1];
+				vo = vo + a + ro;
+			}
+		} else {
+			if (upd_e) {
+				real_t a = CIe(LXYA) * qc[ce] + CIe(LXYB) * qc[ce - sc];
+				ve = ve + a + re;
+			}
+			if (upd_o) {
+				real_t a = CIo(LXYSW) * qc[co - 1 - sc] + CIo(LXYNW) * qc[co - 1]
+				           + CIo(LXYNE) * qc[co] + CIo(LXYSE) * qc[co - sc];
+				vo = vo + a + ro;
+			}
+		}
+	} else {
+		if (!JO) {
+			if (upd_e) ve = ve + CIe(LXZA) * qc[ce] + CIe(LXZB) * qc[ce - tc] + re;
+			if (upd_o)
+				vo = vo + CIo(LXZNW) * qc[co - 1] + CIo(LXZNE) * qc[co]
+				     + CIo(LXZSW) * qc[co - 1 - tc] + CIo(LXZSE) * qc[co - tc] + ro;
+		} else {
+			if (upd_e)
+				ve = ve + CIe(LYZNW) * qc[ce] + CIe(LYZNE) * qc[ce - sc]
+				     + CIe(LYZSW) * qc[ce - tc] + CIe(LYZSE) * qc[ce - sc - tc] + re;
+			if (upd_o)
+				vo = vo + CIo(LTNW) * qc[co - 1] + CIo(LTNE) * qc[co]
+				     + CIo(LTSW) * qc[co - 1 - sc] + CIo(LTSE) * qc[co - sc]
+				     + CIo(LBNW) * qc[co - 1 - tc] + CIo(LBNE) * qc[co - tc]
+				     + CIo(LBSW) * qc[co - 1 - sc - tc] + CIo(LBSE) * qc[co - sc - tc] + ro;
+		}
+	}
+#undef CIe
+#undef CIo
+}
+
 __global__ __launch_bounds__(256) void interp_add3_kernel(real_t *__restrict__ q, const real_t *__restrict__ qc,
                                                            const real_t *__restrict__ so_diag, real_t *__restrict__ res,
                                                            const real_t *__restrict__ ci,
@@ -163,56 +217,52 @@ __global__ __launch_bounds__(256) void interp_add3_kernel(real_t *__restrict__ q
 	const bool jo = j & 1, ko = k & 1;
 	const int jc = jo ? (j + 1) / 2 + 1 : j / 2 + 1, kc = ko ? (k + 1) / 2 + 1 : k / 2 + 1;
 	const bool row_in_range = j <= jmax && k <= (ko ? kmax_o : kmax_e);
-	for (int i = threadIdx.x + 2; i <= IIF; i += blockDim.x) {
-		const size_t x = (size_t)(i - 1) + sf * (size_t)(j - 1) + tf * (size_t)(k - 1);
-		const bool interior = i <= IIF - 1 && j <= JJF - 1 && k <= KKF - 1;
-		const bool io = i & 1;
+	const bool row_interior = j <= JJF - 1 && k <= KKF - 1;
+	const size_t rowf = sf * (size_t)(j - 1) + tf * (size_t)(k - 1);
+	const size_t rowc = sc * (size_t)(jc - 1) + tc * (size_t)(kc - 1);
+	for (int p = threadIdx.x; 2 * p + 2 <= IIF; p += blockDim.x) {
+		const int ie = 2 * p + 2, io = ie + 1; // 1-based
+		const bool have_o = io <= IIF;
+		const size_t x = rowf + (size_t)(ie - 1);
+		const bool int_e = row_interior && ie <= IIF - 1, int_o = row_interior && have_o && io <= IIF - 1;
 		// written range of this plane type: even planes i in [2, imax_all] (all parities);
 		// odd planes: even i up to imax_e, odd i up to imax_all-1
-		const bool upd = row_in_range && (ko ? (io ? i <= imax_all - 1 : i <= imax_e) : i <= imax_all);
-		real_t r = 0.0;
-		if (interior || upd) r = res[x];
-		if (interior) {
-			r = r / so_diag[x];
-			res[x] = r;
-		}
-		if (!upd) continue;
-		const int ic = io ? (i + 1) / 2 + 1 : i / 2 + 1;
-		const size_t c = (size_t)(ic - 1) + sc * (size_t)(jc - 1) + tc * (size_t)(kc - 1);
-#define CIv(slot) ci[(size_t)(slot)*PC + c]
-		real_t v = q[x];
-		if (!ko) {
-			if (!io && !jo) {
-				v = v + qc[c];
-			} else if (io && !jo) {
-				real_t a = CIv(LXYR) * qc[c] + CIv(LXYL) * qc[c - 1];
-				v = v + a + r;
-			} else if (!io && jo) {
-				real_t a = CIv(LXYA) * qc[c] + CIv(LXYB) * qc[c - sc];
-				v = v + a + r;
-			} else {
-				real_t a = CIv(LXYSW) * qc[c - 1 - sc] + CIv(LXYNW) * qc[c - 1]
-				           + CIv(LXYNE) * qc[c] + CIv(LXYSE) * qc[c - sc];
-				v = v + a + r;
-			}
+		const bool upd_e = row_in_range && (ko ? ie <= imax_e : ie <= imax_all);
+		const bool upd_o = row_in_range && have_o && (ko ? io <= imax_all - 1 : io <= imax_all);
+		if (!(int_e || int_o || upd_e || upd_o)) continue;
+		real_t re = 0.0, ro = 0.0, de = 1.0, dn = 1.0, ve = 0.0, vo = 0.0;
+		if (have_o) {
+			d2u t = *reinterpret_cast<const d2u *>(res + x); re = t.x; ro = t.y;
+			t = *reinterpret_cast<const d2u *>(so_diag + x); de = t.x; dn = t.y;
+			t = *reinterpret_cast<const d2u *>(q + x); ve = t.x; vo = t.y;
 		} else {
-			if (!io && !jo) {
-				v = v + CIv(LXZA) * qc[c] + CIv(LXZB) * qc[c - tc] + r;
-			} else if (!io && jo) {
-				v = v + CIv(LYZNW) * qc[c] + CIv(LYZNE) * qc[c - sc]
-				    + CIv(LYZSW) * qc[c - tc] + CIv(LYZSE) * qc[c - sc - tc] + r;
-			} else if (io && !jo) {
-				v = v + CIv(LXZNW) * qc[c - 1] + CIv(LXZNE) * qc[c]
-				    + CIv(LXZSW) * qc[c - 1 - tc] + CIv(LXZSE) * qc[c - tc] + r;
-			} else {
-				v = v + CIv(LTNW) * qc[c - 1] + CIv(LTNE) * qc[c]
-				    + CIv(LTSW) * qc[c - 1 - sc] + CIv(LTSE) * qc[c - sc]
-				    + CIv(LBNW) * qc[c - 1 - tc] + CIv(LBNE) * qc[c - tc]
-				    + CIv(LBSW) * qc[c - 1 - sc - tc] + CIv(LBSE) * qc[c - sc - tc] + r;
-			}
+			re = res[x]; de = so_diag[x]; ve = q[x];
 		}
-#undef CIv
-		q[x] = v;
+		if (int_e) re = re / de;
+		if (int_o) ro = ro / dn;
+		if (int_e && int_o) {
+			d2u t; t.x = re; t.y = ro;
+			*reinterpret_cast<d2u *>(res + x) = t;
+		} else {
+			if (int_e) res[x] = re;
+			if (int_o) res[x + 1] = ro;
+		}
+		if (!(upd_e || upd_o)) continue;
+		const size_t ce = rowc + (size_t)(ie / 2); // 0-based: ic-1 = i/2
+		if (ko) {
+			if (jo) interp_add3_pair<true, true>(ve, vo, re, ro, upd_e, upd_o, qc, ci, ce, sc, tc, PC);
+			else interp_add3_pair<true, false>(ve, vo, re, ro, upd_e, upd_o, qc, ci, ce, sc, tc, PC);
+		} else {
+			if (jo) interp_add3_pair<false, true>(ve, vo, re, ro, upd_e, upd_o, qc, ci, ce, sc, tc, PC);
+			else interp_add3_pair<false, false>(ve, vo, re, ro, upd_e, upd_o, qc, ci, ce, sc, tc, PC);
+		}
+		if (upd_e && upd_o) {
+			d2u t; t.x = ve; t.y = vo;
+			*reinterpret_cast<d2u *>(q + x) = t;
+		} else {
+			if (upd_e) q[x] = ve;
+			if (upd_o) q[x + 1] = vo;
+		}
 	}
 }
 
@@ -227,7 +277,7 @@ void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, con
 	const int kmax_e = 2 * (KKC - 2);       // coarse planes kc = 2..kkc1
 	const int kmax_o = 2 * (kkcf1 - 1) - 1; // odd planes kc = 3..kkcf1
 	unsigned nrows = (unsigned)(JJF - 1) * (unsigned)(KKF - 1);
-	int bs = IIF >= 256 ? 256 : (IIF > 64 ? 128 : 64);
+	int bs = IIF / 2 >= 256 ? 256 : (IIF / 2 > 64 ? 128 : 64); // one lane per column pair
 	hipLaunchKernelGGL(interp_add3_kernel, dim3(xcd_grid(nrows)), dim3(bs), 0, st, q, qc, so /* KP plane */, res, ci,
 	                   IIC, JJC, KKC, IIF, JJF, KKF, imax_e, imax_all, jmax, kmax_e, kmax_o, nrows);
 }
