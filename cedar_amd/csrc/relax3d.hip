@@ -178,9 +178,13 @@ __device__ __forceinline__ void ldpair_so(const real_t *__restrict__ p, bool two
 
 // all operands of the pair (ie, io) of one row: 26 coefficients per point, qf, and the 3x3 q rows
 // (offsets ie-1 .. io+1); 16-byte loads, `two` = element io+1 is still inside the row
-// NTP: the same for the three slots whose rows two row tasks of one plane share (kps, kpsw, kpnw);
-// the plane-fused pass keeps those cacheable so that the second task finds them in L2
-template <bool NT, bool NTP = NT>
+// Load policy (which operator streams bypass the caches with non-temporal loads):
+//   NT  = rows only this task reads in this launch (relax) -- streamed;
+//   NTP = the three slots whose rows two row tasks of one plane share (kps, kpsw, kpnw): the plane-fused
+//         relax pass keeps them cacheable so that the second task finds them in L2 / Infinity Cache;
+//   NTO = the task's own row (offset 0) where that is its LAST use in the launch (residual: the rows at
+//         j+1 / k+1 are read again by the neighbouring task, the own row is not).
+template <bool NT, bool NTP = NT, bool NTO = NT>
 __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                             const real_t *__restrict__ q, size_t row, size_t sj, size_t sk, size_t PS,
                                             int ie, int io, bool two, C27 &ce, C27 &co,
@@ -194,14 +198,18 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 	ce.fe = a_; co.fo = b_;                                                        \
 }
 #define LD_I(slot, off, fe, fo) LD_I_(NT, slot, off, fe, fo)
+#define LD_IO(slot, fe, fo) LD_I_(NTO, slot, 0, fe, fo)
 #define LD_IS(slot, off, fe, fo) LD_I_(NTP, slot, off, fe, fo)
-	LD_I(KPW, 0, pw, pw) LD_IS(KPS, 0, ps, ps) LD_IS(KPSW, 0, psw, psw) LD_I(KB, 0, b, b)
-	LD_I(KBW, 0, bw, bw) LD_I(KBS, 0, bs, bs) LD_I(KBSW, 0, bsw, bsw)
+#define LD_ISO(slot, fe, fo) LD_I_((NTP && NTO), slot, 0, fe, fo)
+	LD_IO(KPW, pw, pw) LD_ISO(KPS, ps, ps) LD_ISO(KPSW, psw, psw) LD_IO(KB, b, b)
+	LD_IO(KBW, bw, bw) LD_IO(KBS, bs, bs) LD_IO(KBSW, bsw, bsw)
 	LD_IS(KPNW, sj, pnw_n, pnw_n) LD_IS(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
 	LD_I(KB, sk, b_t, b_t) LD_I(KBE, sk, be_t, be_t) LD_I(KBN, sk, bn_t, bn_t) LD_I(KBNE, sk, bne_t, bne_t)
 	LD_I(KBSE, sj + sk, bse_nt, bse_nt) LD_I(KBS, sj + sk, bs_nt, bs_nt)
 #undef LD_I
+#undef LD_IO
 #undef LD_IS
+#undef LD_ISO
 #undef LD_I_
 	// ---- [i+1]-pattern streams: (value at ie+1 = io, value at io+1)
 #define LD_IP_(N, slot, off, f)                                                        \
@@ -211,13 +219,17 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 	ce.f = a_; co.f = b_;                                                          \
 }
 #define LD_IP(slot, off, f) LD_IP_(NT, slot, off, f)
+#define LD_IPO(slot, f) LD_IP_(NTO, slot, 0, f)
 #define LD_IPS(slot, off, f) LD_IP_(NTP, slot, off, f)
+#define LD_IPSO(slot, f) LD_IP_((NTP && NTO), slot, 0, f)
 	LD_IPS(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
-	LD_IP(KPW, 0, pw_e) LD_IPS(KPNW, 0, pnw_e) LD_IP(KBE, 0, be_e) LD_IP(KBSE, 0, bse_e)
+	LD_IPO(KPW, pw_e) LD_IPSO(KPNW, pnw_e) LD_IPO(KBE, be_e) LD_IPO(KBSE, bse_e)
 	LD_IP(KBSW, sj + sk, bsw_net)
 	LD_IP(KBW, sk, bw_et) LD_IP(KBNW, sk, bnw_et)
 #undef LD_IP
+#undef LD_IPO
 #undef LD_IPS
+#undef LD_IPSO
 #undef LD_IP_
 	{
 		real_t a_, b_;
@@ -414,8 +426,10 @@ __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__
 		const bool o_ok = io <= II - 2, two = io + 1 <= II - 1;
 		C27 ce, co;
 		real_t qe[3][3][3], qo[3][3][3], qfe, qfo, de, dn;
-		load_pair27<NT>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
-		ldpair(so + row + ie, true, de, dn); // KP plane
+		// NT: the own row's operator entries are streamed (last use in this launch), the rows at j+1 / k+1
+		// stay cacheable for the neighbouring task that reads them as its own
+		load_pair27<false, false, NT>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		ldpair_so<NT>(so + row + ie, true, de, dn); // KP plane
 		const real_t re = offdiag27(qfe, ce, qe) - de * qe[1][1][1];
 		if (o_ok) {
 			const real_t ro = offdiag27(qfo, co, qo) - dn * qo[1][1][1];
@@ -431,8 +445,11 @@ void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t
 	const TileShape ts = tile_shape_resid();
 	unsigned nrows = tile_blocks((unsigned)(JJ - 2), (unsigned)(KK - 2), ts);
 	const int npairs = (II - 2 + 1) / 2;
+	const char *e = getenv("CEDAR_AMD_RESID_NT");
+	const bool nt = e ? atoi(e) != 0 : false;
 	if (npairs <= 64) hipLaunchKernelGGL((residual27_rows<64, false>), dim3(xcd_grid(nrows)), dim3(64), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 	else if (npairs <= 128) hipLaunchKernelGGL((residual27_rows<128, false>), dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+	else if (nt) hipLaunchKernelGGL((residual27_rows<256, true>), dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 	else hipLaunchKernelGGL((residual27_rows<256, false>), dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 }
 
