@@ -126,12 +126,20 @@ def cpu_baseline(wl, relax):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     allc = launch(cores, 8.0) if cores > 1 else [one]
     total = sum(o["dof_per_s"] for o in allc)
     return {"value": total, "unit": "DOF/s", "cores": cores, "kind": one["kind"],
-            "single_core_value": one["dof_per_s"],
+            "single_core_value": one["dof_per_s"], "cpu_model": cpu_model,
             "sample": f"{one['sample']} per rank, V(2,1) cycles for 8 s, {cores} independent single-threaded ranks "
-                      f"(one per host core, no halo cost charged); single rank alone: {one['dof_per_s']:.3e} DOF/s; {one['what']}"}
+                      f"(one per host core of {cpu_model}, no halo cost charged); single rank alone: {one['dof_per_s']:.3e} DOF/s; {one['what']}"}
 
 
 def main():
