@@ -1,0 +1,89 @@
+"""The C++ mirror of Cedar's API surface (include/cedar: config, arrays, grid functions, gallery,
+kernel_manager with the "hip" kernels, cdr2/cdr3::solver) -- drop-in boundary #2 of SURVEY 8b.
+CPU: a host-only program built with g++ (config reader, gallery builders vs tests/problems.py, norms,
+registry semantics).  GPU: the registered "hip" kernels against the oracle bit for bit, and the
+examples (the reference's serial Poisson / periodic programs and a plain-C caller) end to end."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FLAGS = ["-std=c++17", "-O1", "-Wall", f"-I{ROOT}/include", f"-L{ROOT}/cedar_amd/lib", "-lcedar_amd", "-L/opt/rocm/lib",
+         f"-Wl,-rpath,{ROOT}/cedar_amd/lib", "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def build(src, exe):
+    from cedar_amd import capi  # noqa: F401  (builds libcedar_amd.so if missing)
+    subprocess.run(["g++", os.path.join(HERE, "cxx", src)] + FLAGS + ["-o", str(exe)], check=True)
+
+
+def test_host_side_of_the_cxx_mirror(tmp_path):
+    json.dump({"grid": {"n": [300, 200], "periodic": [True, False]},
+               "solver": {"relaxation": "line-xy", "cycle": {"nrelax-pre": 3, "nrelax-post": 2, "type": "f"},
+                          "max-iter": 7, "tol": 1e-9}}, open(tmp_path / "config.json", "w"))
+    exe = tmp_path / "host_checks"
+    build("host_checks.cc", exe)
+    p = subprocess.run([str(exe), str(tmp_path)], check=True, capture_output=True, text=True)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    assert (got["nx"], got["ny"]) == (300, 200)
+    assert got["periodic"] == [1, 0] and got["per_mask"] == 1
+    assert (got["relaxation"], got["pre"], got["post"], got["maxiter"], got["cycle"]) == (3, 3, 2, 7, 1)
+    assert got["tol"] == 1e-9
+    assert got["inf_norm"] == -3.0  # signed entry of largest magnitude, ghosts excluded
+    assert abs(got["l2"] - np.sqrt(0.25 + 9 + 4)) < 1e-15
+    assert (got["r_first"], got["r_hip"], got["r_after_bad"], got["via_run"]) == (6, 35, 35, 42)
+    assert "no implementation named does-not-exist" in p.stderr + p.stdout
+    for name, want in (("poisson2", pb.poisson2(9, 7)), ("diag2", pb.diag_diffusion2(11, 6, 1.0, 1e-4)), ("fe2", pb.fe2(8, 10)),
+                       ("poisson3", pb.poisson3(6, 7, 5)), ("fe3", pb.fe3(5, 6, 7))):
+        a = np.fromfile(tmp_path / f"{name}.bin", dtype=np.float64).reshape(want.shape)
+        assert np.array_equal(a, want), name
+
+
+@pytest.mark.gpu
+def test_registered_hip_kernels_match_the_oracle(tmp_path, oracle):
+    json.dump({}, open(tmp_path / "config.json", "w"))
+    exe = tmp_path / "hip_kernels"
+    build("hip_kernels.cc", exe)
+    subprocess.run([str(exe), str(tmp_path)], check=True)
+    nx, ny = 37, 22
+    g = (ny + 2, nx + 2)
+    so = pb.fe2(nx, ny)
+    x, b = np.zeros(g), np.zeros(g)
+    i = np.arange(1, nx + 1)[None, :]
+    j = np.arange(1, ny + 1)[:, None]
+    x[1:-1, 1:-1] = 0.01 * i - 0.02 * j
+    b[1:-1, 1:-1] = 1.0 / (1 + i + j)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip2(so, sor)
+    oracle.relax2(so, b, x, sor, 0)
+    oracle.relax2(so, b, x, sor, 1)
+    r = np.zeros(g)
+    oracle.residual2(so, b, x, r)
+    assert np.array_equal(np.fromfile(tmp_path / "x.bin").reshape(g), x)
+    assert np.array_equal(np.fromfile(tmp_path / "r.bin").reshape(g), r)
+
+
+@pytest.mark.gpu
+def test_examples_end_to_end(tmp_path):
+    ex = os.path.join(ROOT, "examples")
+    subprocess.run(["make", "-C", ex], check=True, capture_output=True)
+    json.dump({"grid": {"n": [200, 200]}}, open(tmp_path / "config.json", "w"))
+    with open(os.path.join(ex, "periodic-config.json")) as f:
+        open(tmp_path / "periodic-config.json", "w").write(f.read())
+    d3 = tmp_path / "d3"  # no config.json there: the 3D example's default 64^3 grid
+    d3.mkdir()
+    for exe, args in (("ser-poisson-2d", []), ("ser-poisson-3d", []), ("ser-periodic-2d", []), ("capi-poisson-2d", ["200"])):
+        p = subprocess.run([os.path.join(ex, exe)] + args, cwd=d3 if exe == "ser-poisson-3d" else tmp_path,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, (exe, p.stdout[-400:], p.stderr[-400:])
+        text = p.stdout + p.stderr
+        if exe.startswith("ser-"):
+            m = re.search(r"Solution norm: (\S+)", text)
+            assert m and abs(float(m.group(1))) < 1e-2, (exe, text[-300:])
