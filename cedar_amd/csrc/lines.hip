@@ -330,17 +330,17 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
 template <bool NINE>
 __global__ __launch_bounds__(256) void ylines_rhs_T(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                      const real_t *__restrict__ q, real_t *__restrict__ bt,
-                                                     int II, int JJ, int ib, int nlines, int ldt)
+                                                     int II, int JJ, int ib, int nlines, int ldt, int lofs)
 {
 	__shared__ real_t tile[32][33];
-	const int l0 = blockIdx.x * 32, j0 = blockIdx.y * 32; // tile origin (line index, j-1)
+	const int l0 = blockIdx.x * 32, j0 = blockIdx.y * 32; // tile origin (line index within the chunk, j-1)
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
 	const size_t sj = II, PS = (size_t)II * JJ;
 	for (int r = ty; r < 32; r += 8) {
 		const int l = l0 + tx, j = j0 + r + 1;
 		real_t s = 0.0;
 		if (l < nlines && j <= JJ - 2) {
-			const size_t x = (size_t)(1 + ib + 2 * l) + sj * (size_t)j;
+			const size_t x = (size_t)(1 + ib + 2 * (lofs + l)) + sj * (size_t)j;
 			// relax_lines_y.f90:103-107 / :133-134, reference term order
 			s = qf[x];
 			s = s + so[KW * PS + x] * q[x - 1];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void ylines_rhs_T(const real_t *__restrict__ s
 template <int BS, bool SM = false>
 __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, const real_t *__restrict__ sor,
                                                     int II, int JJ, int ib, int nlines, int ldt,
-                                                    const real_t *__restrict__ so = nullptr)
+                                                    const real_t *__restrict__ so, int lofs)
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int n = JJ - 2;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, cons
 	const unsigned L = blockIdx.x;
 	if (L >= (unsigned)nlines) return;
 	const size_t PS = (size_t)II * JJ;
-	const int i = 1 + ib + 2 * (int)L; // 0-based line position
+	const int i = 1 + ib + 2 * (lofs + (int)L); // 0-based line position
 	real_t *line = bt + (size_t)L * ldt;
 	for (int t = threadIdx.x; t < n; t += BS) y[lpad(t)] = line[t];
 	__syncthreads();
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, cons
 }
 
 __global__ __launch_bounds__(256) void ylines_scatter_T(const real_t *__restrict__ bt, real_t *__restrict__ q,
-                                                         int II, int JJ, int ib, int nlines, int ldt)
+                                                         int II, int JJ, int ib, int nlines, int ldt, int lofs)
 {
 	__shared__ real_t tile[32][33];
 	const int l0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void ylines_scatter_T(const real_t *__restrict
 	__syncthreads();
 	for (int r = ty; r < 32; r += 8) {
 		const int l = l0 + tx, j = j0 + r + 1;
-		if (l < nlines && j <= JJ - 2) q[(size_t)(1 + ib + 2 * l) + (size_t)II * j] = tile[tx][r];
+		if (l < nlines && j <= JJ - 2) q[(size_t)(1 + ib + 2 * (lofs + l)) + (size_t)II * j] = tile[tx][r];
 	}
 }
 
@@ -423,28 +423,36 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	const int n = JJ - 2;
 	const int ldt = (n + 15) & ~15;
 	const size_t shm = line_lds_doubles(n) * sizeof(real_t);
+	// the lines of a colour go through gather -> solve -> scatter in chunks whose line-contiguous scratch
+	// (chunk * ldt doubles) stays in the Infinity Cache between the three kernels
+	const char *ce = getenv("CEDAR_AMD_YCHUNK");
+	const int chunk_lines = ce ? atoi(ce) : 512; // 8192^2: 20.6 (whole colour) -> 19.8 ms per V-cycle (profiles/r01_experiment_yline_chunks.log)
 	for (int c = 0; c < 2; c++) {
 		int ib = (updown == BMG_DOWN) ? 1 - c : c; // DOWN: I = 3,5,.. first
-		int nlines = (II - 2 - ib + 1) / 2;
-		if (nlines <= 0) continue;
-		dim3 tg((nlines + 31) / 32, (n + 31) / 32);
-		if (nstncl == 5)
-			hipLaunchKernelGGL(ylines_rhs_T<true>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
-		else
-			hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt);
-		if (n <= 512) {
-			if (sm) hipLaunchKernelGGL((ylines_solve<64, true>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
-			else hipLaunchKernelGGL((ylines_solve<64, false>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
-		} else if (sm) {
-			auto k = ylines_solve<256, true>;
-			if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-			hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
-		} else {
-			auto k = ylines_solve<256, false>;
-			if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-			hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so);
+		int nall = (II - 2 - ib + 1) / 2;
+		if (nall <= 0) continue;
+		const int step = chunk_lines > 0 ? chunk_lines : nall;
+		for (int lofs = 0; lofs < nall; lofs += step) {
+			const int nlines = nall - lofs < step ? nall - lofs : step;
+			dim3 tg((nlines + 31) / 32, (n + 31) / 32);
+			if (nstncl == 5)
+				hipLaunchKernelGGL(ylines_rhs_T<true>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt, lofs);
+			else
+				hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt, lofs);
+			if (n <= 512) {
+				if (sm) hipLaunchKernelGGL((ylines_solve<64, true>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
+				else hipLaunchKernelGGL((ylines_solve<64, false>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
+			} else if (sm) {
+				auto k = ylines_solve<256, true>;
+				if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+				hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
+			} else {
+				auto k = ylines_solve<256, false>;
+				if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+				hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
+			}
+			hipLaunchKernelGGL(ylines_scatter_T, tg, dim3(256), 0, st, bt, q, II, JJ, ib, nlines, ldt, lofs);
 		}
-		hipLaunchKernelGGL(ylines_scatter_T, tg, dim3(256), 0, st, bt, q, II, JJ, ib, nlines, ldt);
 		if (sm) wrap2(q, II, JJ, 1, 1, ipn == 3, st);
 	}
 	if (ipn == 2) wrap2(q, II, JJ, 1, 0, 1, st);
