@@ -388,6 +388,40 @@ void cedar_amd_relax3_pass_part(real_t *so, real_t *qf, real_t *q, real_t *sor, 
 	relax3_pass27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, jb, kb, efirst, current_stream(), part);
 }
 
+void cedar_amd_relax2_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int jb, int efirst)
+{
+	size_t P = (size_t)ii * jj;
+	Staged sso(so, P * 5, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax2_pass9(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, jb, efirst, current_stream());
+}
+
+void cedar_amd_relax2_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int icol, int jb)
+{
+	size_t P = (size_t)ii * jj;
+	Staged sso(so, P * 5, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax2_fixup9(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, icol, jb, current_stream());
+}
+
+void cedar_amd_relax2_colour5(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int jo)
+{
+	size_t P = (size_t)ii * jj;
+	Staged sso(so, P * 3, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax2_colour5(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, jo, current_stream());
+}
+
+void cedar_amd_setup_interp2_phase(real_t *so, real_t *ci, len_t iif, len_t jjf, len_t iic, len_t jjc,
+                                   int ifd, int nstncl, int phase, int ilo, int jlo)
+{
+	size_t P = (size_t)iif * jjf, PC = (size_t)iic * jjc;
+	Staged sso(so, P * nstncl, true, false), sci(ci, PC * 8, true, true);
+	setup_interp2_phase(sso.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, phase, ilo, jlo, current_stream());
+}
+
+void cedar_amd_affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse)
+{
+	affine_lines(y, a, div, nlines, n, ld, reverse, current_stream());
+}
+
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb)
 {

@@ -66,6 +66,16 @@ void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int nstncl, hipStream_t st);
 void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int KK, int nstncl, hipStream_t st);
+// pieces of the 2D sweep / set-up for domain-decomposed runs (relax2d.hip, setup_interp.hip)
+void relax2_pass9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                  int II, int JJ, int jb, int efirst, hipStream_t st);
+void relax2_fixup9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int icol, int jb, hipStream_t st);
+void relax2_colour5(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    int II, int JJ, int jo, hipStream_t st);
+void setup_interp2_phase(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, int phase,
+                         int ilo, int jlo, hipStream_t st);
+void affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse, hipStream_t st);
 // 2D periodic boundary conditions (periodic2d.hip); ipn = 1 per_y, 2 per_x, 3 per_xy
 void wrap2(real_t *q, int II, int JJ, int nplanes, int do_y, int do_x, hipStream_t st);
 int relax2_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,

@@ -200,6 +200,55 @@ __device__ __forceinline__ void line_pttrs(real_t *y, int n, const real_t *__res
 	}
 }
 
+// Generic first-order recurrence over line-contiguous data, one workgroup per line:
+//   forward  (reverse = 0): y_i = a_i * y_{i-1} + c_i,  i = 0..n-1,   y_{-1} = 0
+//   backward (reverse = 1): y_i = a_i * y_{i+1} + c_i,  i = n-1..0,   y_n    = 0
+// with c_i = y_i on entry, divided by div_i when div != nullptr.  The two sweeps of DPTTRS are the cases
+// (a = -e', div = nullptr) and (a = -e'_next, div = d', reverse); the domain-decomposed line relaxation
+// (cedar_amd/dist2d.py) runs them per segment and joins the segments' carries across ranks.
+template <int BS>
+__global__ __launch_bounds__(BS) void affine_lines_kernel(real_t *__restrict__ y, const real_t *__restrict__ a,
+                                                           const real_t *__restrict__ div, int n, int ld, int reverse)
+{
+	__shared__ real_t wa[4], wc[4], cs;
+	real_t *line = y + (size_t)blockIdx.x * ld;
+	const real_t *al = a + (size_t)blockIdx.x * ld;
+	const real_t *dl = div ? div + (size_t)blockIdx.x * ld : nullptr;
+	real_t carry = 0.0;
+	for (int base = 0; base < n; base += BS * CH) {
+		const int r0 = base + (int)threadIdx.x * CH;
+		real_t am[CH], cm[CH];
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			const int r = r0 + m, i = reverse ? n - 1 - r : r;
+			if (r < n) { cm[m] = dl ? line[i] / dl[i] : line[i]; am[m] = al[i]; }
+			else { cm[m] = 0.0; am[m] = 0.0; }
+		}
+		real_t A = 1.0, Cc = 0.0;
+#pragma unroll
+		for (int m = 0; m < CH; m++) { Cc = am[m] * Cc + cm[m]; A = am[m] * A; }
+		real_t v, last;
+		affine_scan<BS>(A, Cc, carry, wa, wc, v, last);
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			v = am[m] * v + cm[m];
+			const int r = r0 + m;
+			if (r < n) line[reverse ? n - 1 - r : r] = v;
+		}
+		if (threadIdx.x == BS - 1) cs = last;
+		__syncthreads();
+		carry = cs;
+		__syncthreads();
+	}
+}
+
+void affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse, hipStream_t st)
+{
+	if (nlines <= 0 || n <= 0) return;
+	if (n <= 512) hipLaunchKernelGGL(affine_lines_kernel<64>, dim3(nlines), dim3(64), 0, st, y, a, div, n, ld, reverse);
+	else hipLaunchKernelGGL(affine_lines_kernel<256>, dim3(nlines), dim3(256), 0, st, y, a, div, n, ld, reverse);
+}
+
 // doubles of LDS a line of n unknowns needs (padded line + scan scratch)
 static inline size_t line_lds_doubles(int n) { return (size_t)n + (size_t)(n >> 3) + 24; }
 

@@ -200,32 +200,76 @@ __global__ __launch_bounds__(256) void relax5_colour(const real_t *__restrict__ 
 	q[x] = s * sor[PS + x];
 }
 
+// one row class (jb = parity of the 0-based row minus 1) of the nine-point sweep, both i-colours;
+// efirst: even 1-based i first (the DOWN order of the 2D sweep).  Domain-decomposed runs exchange
+// halos between row classes.
+void relax2_pass9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                  int II, int JJ, int jb, int efirst, hipStream_t st)
+{
+	int nrows = (JJ - 2 - jb + 1) / 2;
+	if (nrows <= 0) return;
+	unsigned grid = xcd_grid((unsigned)nrows);
+	const int npairs = (II - 2 + 1) / 2;
+	if (npairs <= 64) {
+		if (efirst) hipLaunchKernelGGL((relax9_rows<64, true>), dim3(grid), dim3(64), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
+		else hipLaunchKernelGGL((relax9_rows<64, false>), dim3(grid), dim3(64), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
+	} else {
+		if (efirst) hipLaunchKernelGGL((relax9_rows<256, true>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
+		else hipLaunchKernelGGL((relax9_rows<256, false>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
+	}
+}
+
+// recompute the points of column icol (0-based incl. ghost) on the rows of class jb: used after the
+// x-neighbour's fresh first colour arrived (the update of a point does not read its own old value)
+__global__ void relax9_column(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                              real_t *__restrict__ q, const real_t *__restrict__ sor,
+                              int II, int JJ, int icol, int jb)
+{
+	const int nrows = (JJ - 2 - jb + 1) / 2;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nrows) return;
+	const size_t sj = II, PS = (size_t)II * JJ;
+	const size_t x = (size_t)icol + sj * (size_t)(1 + jb + 2 * t);
+	real_t s = qf[x];
+	s = s + so[KW * PS + x] * q[x - 1];
+	s = s + so[KW * PS + x + 1] * q[x + 1];
+	s = s + so[KS * PS + x] * q[x - sj];
+	s = s + so[KS * PS + x + sj] * q[x + sj];
+	s = s + so[KSW * PS + x] * q[x - 1 - sj];
+	s = s + so[KNW * PS + x + 1] * q[x + 1 - sj];
+	s = s + so[KNW * PS + x + sj] * q[x - 1 + sj];
+	s = s + so[KSW * PS + x + 1 + sj] * q[x + 1 + sj];
+	q[x] = s * sor[PS + x];
+}
+
+void relax2_fixup9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int icol, int jb, hipStream_t st)
+{
+	const int nrows = (JJ - 2 - jb + 1) / 2;
+	if (nrows <= 0) return;
+	hipLaunchKernelGGL(relax9_column, dim3((nrows + 127) / 128), dim3(128), 0, st, so, qf, q, sor, II, JJ, icol, jb);
+}
+
+// one colour of the five-point red-black sweep: jo in {2,3}, points with mod(i+j+jo,2) == 0 (1-based)
+void relax2_colour5(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    int II, int JJ, int jo, hipStream_t st)
+{
+	if (II < 3 || JJ < 3) return;
+	dim3 grid(((II - 2 + 1) / 2 + 255) / 256, JJ - 2);
+	hipLaunchKernelGGL(relax5_colour, grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jo);
+}
+
 void relax2_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int nstncl, int updown, hipStream_t st)
 {
 	if (II < 3 || JJ < 3) return;
 	const bool down = (updown == BMG_DOWN);
 	if (nstncl == 5) {
-		for (int c = 0; c < 2; c++) {
-			int jb = down ? c : 1 - c;  // DOWN: rows J=2,4,.. first (LSTART=2)
-			int nrows = (JJ - 2 - jb + 1) / 2;
-			if (nrows <= 0) continue;
-			unsigned grid = xcd_grid((unsigned)nrows);
-			const int npairs = (II - 2 + 1) / 2;
-			if (npairs <= 64) {
-				if (down) hipLaunchKernelGGL((relax9_rows<64, true>), dim3(grid), dim3(64), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-				else hipLaunchKernelGGL((relax9_rows<64, false>), dim3(grid), dim3(64), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-			} else {
-				if (down) hipLaunchKernelGGL((relax9_rows<256, true>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-				else hipLaunchKernelGGL((relax9_rows<256, false>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-			}
-		}
+		for (int c = 0; c < 2; c++) // DOWN: rows J=2,4,.. first (LSTART=2), even 1-based i first
+			relax2_pass9(so, qf, q, sor, II, JJ, down ? c : 1 - c, down, st);
 	} else {
-		for (int c = 0; c < 2; c++) {
-			int jo = down ? 2 + c : 3 - c; // LSTART..LEND
-			dim3 grid(((II - 2 + 1) / 2 + 255) / 256, JJ - 2);
-			hipLaunchKernelGGL(relax5_colour, grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jo);
-		}
+		for (int c = 0; c < 2; c++)
+			relax2_colour5(so, qf, q, sor, II, JJ, down ? 2 + c : 3 - c /* LSTART..LEND */, st);
 	}
 }
 

@@ -32,10 +32,9 @@ __device__ __forceinline__ real_t lump(real_t off, real_t diag, real_t s, real_t
 #define CIW(ic, jc, s) ci[(size_t)((ic)-1) + (size_t)IIC * ((size_t)((jc)-1) + (size_t)JJC * (size_t)(s))]
 
 __global__ __launch_bounds__(256) void interp2_edges(const real_t *__restrict__ so, real_t *ci,
-        int IIF, int JJF, int IIC, int JJC, int ifd)
+        int IIF, int JJF, int IIC, int JJC, int ifd, int ilo, int jlo)
 {
 	const real_t zeps = DBL_EPSILON;
-	const int ilo = 3, jlo = 3; // serial bounds (2D has no distributed variant)
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2; // 1-based
 	const int IIC1 = IIC - 1, JJC1 = JJC - 1;
 	const int IICF1 = (IIF - 2) / 2 + 2, JJCF1 = (JJF - 2) / 2 + 2;
@@ -78,10 +77,9 @@ __global__ __launch_bounds__(256) void interp2_edges(const real_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void interp2_centres(const real_t *__restrict__ so, real_t *ci,
-        int IIF, int JJF, int IIC, int JJC, int ifd)
+        int IIF, int JJF, int IIC, int JJC, int ifd, int ilo, int jlo)
 {
 	const real_t zeps = DBL_EPSILON;
-	const int ilo = 3, jlo = 3; // serial bounds (2D has no distributed variant)
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 2, jc = blockIdx.y + 2; // 1-based
 	const int IIC1 = IIC - 1, JJC1 = JJC - 1;
 	const int IICF1 = (IIF - 2) / 2 + 2, JJCF1 = (JJF - 2) / 2 + 2;
@@ -137,12 +135,21 @@ __global__ __launch_bounds__(256) void interp2_centres(const real_t *__restrict_
 	}
 }
 
-void setup_interp2(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, hipStream_t st)
+// phase 0 = the two edge families, 1 = the cell centres; ilo / jlo = 3 (serial / physical boundary) or 2
+// (a neighbouring subdomain owns coarse index 1), as in setup_interp3_phase
+void setup_interp2_phase(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, int phase,
+                         int ilo, int jlo, hipStream_t st)
 {
 	if (IIC < 2 || JJC < 2) return;
 	dim3 grid((IIC - 1 + 255) / 256, JJC - 1); // ic, jc in [2, IIC], [2, JJC]
-	hipLaunchKernelGGL(interp2_edges, grid, dim3(256), 0, st, so, ci, IIF, JJF, IIC, JJC, ifd);
-	hipLaunchKernelGGL(interp2_centres, grid, dim3(256), 0, st, so, ci, IIF, JJF, IIC, JJC, ifd);
+	if (phase == 0) hipLaunchKernelGGL(interp2_edges, grid, dim3(256), 0, st, so, ci, IIF, JJF, IIC, JJC, ifd, ilo, jlo);
+	else hipLaunchKernelGGL(interp2_centres, grid, dim3(256), 0, st, so, ci, IIF, JJF, IIC, JJC, ifd, ilo, jlo);
+}
+
+void setup_interp2(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, hipStream_t st)
+{
+	setup_interp2_phase(so, ci, IIF, JJF, IIC, JJC, ifd, 0, 3, 3, st);
+	setup_interp2_phase(so, ci, IIF, JJF, IIC, JJC, ifd, 1, 3, 3, st);
 }
 #undef SO
 #undef CIW

@@ -345,6 +345,75 @@ class GpuBackend:
                 capi.lib.cedar_amd_solver_vcycle(h.s.h, x.data_ptr(), b.data_ptr())
         return _H()
 
+    # ---- 2D (cedar_amd/dist2d.py)
+    @staticmethod
+    def _dims2(t):
+        JJ, II = t.shape[-2:]
+        return C.c_uint(II), C.c_uint(JJ)
+
+    def relax_pass2(self, A, b, x, sor, jb, efirst):
+        self.lib.cedar_amd_relax2_pass(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims2(x), jb, int(efirst))
+
+    def relax_fixup2(self, A, b, x, sor, icol, jb):
+        self.lib.cedar_amd_relax2_fixup(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims2(x), icol, jb)
+
+    def relax_colour5(self, A, b, x, sor, jo):
+        self.lib.cedar_amd_relax2_colour5(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims2(x), jo)
+
+    def recip2(self, A, sor):
+        self.lib.BMG2_SymStd_SETUP_recip(self._p(A), self._p(sor), *self._dims2(sor), A.shape[0], 2)
+
+    def residual2(self, A, x, b, r):
+        nst = A.shape[0]
+        II, JJ = self._dims2(x)
+        i = lambda v: C.byref(C.c_int(v))
+        self.lib.BMG2_SymStd_residual(i(0), self._p(A), self._p(b), self._p(x), self._p(r), C.byref(II), C.byref(JJ),
+                                      i(0), i(int(nst == 3)), i(nst), i(0), i(0), i(0), i(0))
+
+    def restrict2(self, r, bc, P):
+        JJ, II = r.shape
+        JJC, IIC = bc.shape
+        self.lib.BMG2_SymStd_restrict(self._p(r), self._p(bc), self._p(P), II, JJ, IIC, JJC, 0)
+
+    def interp_add2(self, x, xc, A, r, P):
+        self.lib.BMG2_SymStd_interp_add(self._p(x), self._p(xc), self._p(r), self._p(A), self._p(P),
+                                        *self._dims2(xc), *self._dims2(x), A.shape[0], 0)
+
+    def interp_phase2(self, A, P, phase, lo):
+        nst = A.shape[0]
+        self.lib.cedar_amd_setup_interp2_phase(self._p(A), self._p(P), *self._dims2(A), *self._dims2(P),
+                                               int(nst == 3), nst, phase, lo[0], lo[1])
+
+    def galerkin2(self, A, Ac, P):
+        nst = A.shape[0]
+        self.lib.BMG2_SymStd_SETUP_ITLI_ex(self._p(A), self._p(Ac), self._p(P), *self._dims2(A), *self._dims2(Ac),
+                                           int(nst == 3), nst, 0)
+
+    def make_serial2(self, gA, relax, pre, post, min_coarse, num_levels):
+        capi = self.capi
+
+        class _H:
+            def __init__(h):
+                h.s = capi.Solver(gA, relax=relax, nrelax_pre=pre, nrelax_post=post, min_coarse=min_coarse,
+                                  num_levels=num_levels, share_operator=True)
+
+            def vcycle(h, x, b):
+                capi.lib.cedar_amd_solver_vcycle(h.s.h, x.data_ptr(), b.data_ptr())
+        return _H()
+
+    def sumsq2(self, r):
+        v = self.capi.lib.cedar_amd_l2norm(r.data_ptr(), r.shape[1], r.shape[0], 1)
+        return v * v
+
+    def affine_lines(self, c, a, div, reverse):
+        """y_i = a_i y_prev + c_i (/ div_i) per row of the (lines, n) tensors; returns y (new tensor)"""
+        y = c.clone()
+        nl, n = y.shape
+        a = a.contiguous()
+        self.lib.cedar_amd_affine_lines(self._p(y), self._p(a), self._p(div.contiguous()) if div is not None else None,
+                                        nl, n, n, int(bool(reverse)))
+        return y
+
     def box_copy(self, arr, nplanes, nboxes, boxes, offs, buf, unpack):
         KK, JJ, II = arr.shape[-3:]
         self.lib.cedar_amd_box_copy(self._p(arr), C.c_uint(II), C.c_uint(JJ), C.c_uint(KK), nplanes, nboxes,

@@ -163,6 +163,20 @@ void cedar_amd_setup_interp3_phase(real_t *so, real_t *ci, len_t iif, len_t jjf,
                                    len_t iic, len_t jjc, len_t kkc, int ifd, int nstncl, int phase,
                                    int ilo, int jlo, int klo);
 
+/* the 2D counterparts (src/2d/ftn/mpi/BMG2_SymStd_relax_GS.f90, ..._SETUP_interp_OI.f90): one row class of
+ * the nine-point sweep (jb in {0,1}; efirst != 0: even 1-based i first = the 2D DOWN order), the column
+ * fix-up after the x-neighbour's first colour arrived, one colour of the five-point sweep (jo in {2,3}),
+ * one phase (0 edges, 1 centres) of the interpolation set-up with lower loop bounds ilo, jlo (3 | 2) */
+void cedar_amd_relax2_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int jb, int efirst);
+void cedar_amd_relax2_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int icol, int jb);
+void cedar_amd_relax2_colour5(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int jo);
+void cedar_amd_setup_interp2_phase(real_t *so, real_t *ci, len_t iif, len_t jjf, len_t iic, len_t jjc,
+                                   int ifd, int nstncl, int phase, int ilo, int jlo);
+/* first-order recurrences over `nlines` line-contiguous vectors (leading dimension ld), in place, device
+ * pointers: forward y_i = a_i y_{i-1} + c_i (reverse = 0) or backward y_i = a_i y_{i+1} + c_i (reverse = 1)
+ * from a zero carry, c_i = y_i on entry (divided by div_i when div != NULL).  The two sweeps of DPTTRS per
+ * line segment for the domain-decomposed line relaxation (src/2d/ftn/mpi/BMG2_SymStd_relax_lines_x.f90). */
+void cedar_amd_affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse);
 /* pack (unpack = 0) / unpack (1) up to 26 sub-boxes of a device array (nplanes x kk x jj x ii) to /
  * from one contiguous device buffer in one launch: boxes = {i0,j0,k0,ni,nj,nk} per box (0-based incl.
  * ghost), offsets[b] = start of box b in the buffer in doubles per plane (box b occupies

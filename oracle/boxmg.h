@@ -67,6 +67,12 @@ void orc2_interp_add(real_t *q, const real_t *qc, real_t *res, const real_t *so,
                      const real_t *ci, len_t IIC, len_t JJC, len_t IIF, len_t JJF);
 void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
                        len_t IIC, len_t JJC, int ifd);
+void orc2_setup_interp_ex(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
+                          len_t IIC, len_t JJC, int ifd, int phase_mask, int ilo, int jlo);
+void orc2_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, int ifd, int pts);
+void orc2_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, int i, int jb);
 void orc2_galerkin(const real_t *so, real_t *soc, const real_t *ci, len_t IIF, len_t JJF,
                    len_t IIC, len_t JJC, int ifd);
 int orc2_setup_cg(const real_t *so, len_t II, len_t JJ, int nstncl,

@@ -82,6 +82,33 @@ void orc2_relax_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	}
 }
 
+/* one colour of the sweep: what a domain-decomposed run does between two halo exchanges
+ * (src/2d/ftn/mpi/BMG2_SymStd_relax_GS.f90).  Nine point: pts = ib + 2 jb, the points with
+ * i = 2+ib, 4+ib, .. on the rows j = 2+jb, 4+jb, ..; five point: pts = jo in {2,3}. */
+void orc2_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, int ifd, int pts)
+{
+	int I1 = (int)II - 1, J1 = (int)JJ - 1;
+	if (ifd != 1) {
+		for (int j = 2 + pts / 2; j <= J1; j += 2)
+			for (int i = 2 + pts % 2; i <= I1; i += 2)
+				Q(i, j) = gs9(so, qf, q, sor, II, JJ, i, j);
+	} else {
+		for (int j = 2; j <= J1; j++)
+			for (int i = (j + pts) % 2 + 2; i <= I1; i += 2)
+				Q(i, j) = gs5(so, qf, q, sor, II, JJ, i, j);
+	}
+}
+
+/* recompute the nine-point points of 1-based column i on the rows of class jb */
+void orc2_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, int i, int jb)
+{
+	int J1 = (int)JJ - 1;
+	for (int j = 2 + jb; j <= J1; j += 2)
+		Q(i, j) = gs9(so, qf, q, sor, II, JJ, i, j);
+}
+
 /* src/2d/ftn/BMG2_SymStd_SETUP_lines_x.f90:68-87 */
 void orc2_setup_lines_x(const real_t *so, real_t *sor, len_t II, len_t JJ)
 {
@@ -412,44 +439,37 @@ static void ci_centre(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t 
 }
 #undef CIW
 
-/* src/2d/ftn/BMG2_SymStd_SETUP_interp_OI.f90:84-256 (non-periodic) */
-void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
-                       len_t IIC, len_t JJC, int ifd)
+/* src/2d/ftn/BMG2_SymStd_SETUP_interp_OI.f90:84-256 (non-periodic).  phase_mask: 1 = the two edge
+ * families, 2 = the cell centres; ilo / jlo: first coarse index of the "between two coarse points"
+ * loops, 3 in the serial code, 2 on a side where a neighbouring subdomain owns coarse index 1 (the
+ * domain-decomposed driver, as in the 3D variant). */
+void orc2_setup_interp_ex(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
+                          len_t IIC, len_t JJC, int ifd, int phase_mask, int ilo, int jlo)
 {
 	int IIC1 = (int)IIC - 1, JJC1 = (int)JJC - 1;
 	int IICF1 = ((int)IIF - 2) / 2 + 2, JJCF1 = ((int)JJF - 2) / 2 + 2;
-	int i, j;
 
-	/* x-edges: fine points between two coarse points on a coarse row (:112-130 / :196-213) */
-	j = 0;
-	for (int jc = 2; jc <= JJC1; jc++) {
-		j += 2;
-		i = 2;
-		for (int ic = 3; ic <= IICF1; ic++) {
-			i += 2;
-			ci_xedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
-		}
-	}
-	/* y-edges (:131-149 / :214-231) */
-	j = 2;
-	for (int jc = 3; jc <= JJCF1; jc++) {
-		j += 2;
-		i = 0;
-		for (int ic = 2; ic <= IIC1; ic++) {
-			i += 2;
-			ci_yedge(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
-		}
+	if (phase_mask & 1) {
+		/* x-edges: fine points between two coarse points on a coarse row (:112-130 / :196-213) */
+		for (int jc = 2; jc <= JJC1; jc++)
+			for (int ic = ilo; ic <= IICF1; ic++)
+				ci_xedge(so, ci, IIF, JJF, IIC, JJC, ifd, 2 * (ic - 1), 2 * (jc - 1), ic, jc);
+		/* y-edges (:131-149 / :214-231) */
+		for (int jc = jlo; jc <= JJCF1; jc++)
+			for (int ic = 2; ic <= IIC1; ic++)
+				ci_yedge(so, ci, IIF, JJF, IIC, JJC, ifd, 2 * (ic - 1), 2 * (jc - 1), ic, jc);
 	}
 	/* cell centres (:150-188 / :232-255) */
-	j = 2;
-	for (int jc = 3; jc <= JJCF1; jc++) {
-		j += 2;
-		i = 2;
-		for (int ic = 3; ic <= IICF1; ic++) {
-			i += 2;
-			ci_centre(so, ci, IIF, JJF, IIC, JJC, ifd, i, j, ic, jc);
-		}
-	}
+	if (phase_mask & 2)
+		for (int jc = jlo; jc <= JJCF1; jc++)
+			for (int ic = ilo; ic <= IICF1; ic++)
+				ci_centre(so, ci, IIF, JJF, IIC, JJC, ifd, 2 * (ic - 1), 2 * (jc - 1), ic, jc);
+}
+
+void orc2_setup_interp(const real_t *so, real_t *ci, len_t IIF, len_t JJF,
+                       len_t IIC, len_t JJC, int ifd)
+{
+	orc2_setup_interp_ex(so, ci, IIF, JJF, IIC, JJC, ifd, 3, 3, 3);
 }
 
 /* the fine index the periodic driver pairs with the next coarse index: I <- MAX(MOD(I+2,IIFC), MIN(I+2,3))

@@ -57,6 +57,19 @@ class Oracle:
         else:
             self.L.orc2_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), updown)
 
+    def relax_colour2(self, so, qf, q, sor, pts):
+        nst, JJ, II = so.shape
+        self.L.orc2_relax_colour(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), int(nst == 3), pts)
+
+    def relax_column2(self, so, qf, q, sor, i1, jb):
+        nst, JJ, II = so.shape
+        self.L.orc2_relax_column(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), i1, jb)
+
+    def setup_interp2_ex(self, so, ci, phase_mask, lo):
+        nst, JJ, II = so.shape
+        _, JJC, IIC = ci.shape
+        self.L.orc2_setup_interp_ex(_p(so), _p(ci), u(II), u(JJ), u(IIC), u(JJC), int(nst == 3), phase_mask, lo[0], lo[1])
+
     def setup_lines2(self, so, sor, d, ibc=0):
         _, JJ, II = so.shape
         if ibc:

@@ -75,6 +75,65 @@ class CpuBackend:
                 h.ml.vcycle(x.numpy(), b.numpy())
         return _H()
 
+    # ---- 2D (cedar_amd/dist2d.py)
+    def relax_pass2(self, A, b, x, sor, jb, efirst):
+        for ib in ((0, 1) if efirst else (1, 0)):
+            self.O.relax_colour2(self._n(A), self._n(b), self._n(x), self._n(sor), ib + 2 * jb)
+
+    def relax_fixup2(self, A, b, x, sor, icol, jb):
+        self.O.relax_column2(self._n(A), self._n(b), self._n(x), self._n(sor), icol + 1, jb)
+
+    def relax_colour5(self, A, b, x, sor, jo):
+        self.O.relax_colour2(self._n(A), self._n(b), self._n(x), self._n(sor), jo)
+
+    def recip2(self, A, sor):
+        self.O.setup_recip2(self._n(A), self._n(sor))
+
+    def residual2(self, A, x, b, r):
+        self.O.residual2(self._n(A), self._n(b), self._n(x), self._n(r))
+
+    def restrict2(self, r, bc, P):
+        self.O.restrict2(self._n(r), self._n(bc), self._n(P))
+
+    def interp_add2(self, x, xc, A, r, P):
+        self.O.interp_add2(self._n(x), self._n(xc), self._n(r), self._n(A), self._n(P))
+
+    def interp_phase2(self, A, P, phase, lo):
+        self.O.setup_interp2_ex(self._n(A), self._n(P), 1 << phase, lo)
+
+    def galerkin2(self, A, Ac, P):
+        self.O.galerkin2(self._n(A), self._n(Ac), self._n(P))
+
+    def make_serial2(self, gA, relax, pre, post, min_coarse, num_levels):
+        O = self.O
+
+        class _H:
+            def __init__(h):
+                h.ml = O.ml_create(gA.numpy(), relax=relax, nrelax_pre=pre, nrelax_post=post, min_coarse=min_coarse,
+                                   num_levels=num_levels)
+
+            def vcycle(h, x, b):
+                h.ml.vcycle(x.numpy(), b.numpy())
+        return _H()
+
+    def sumsq2(self, r):
+        v = self.O.l2(self._n(r))
+        return v * v
+
+    def affine_lines(self, c, a, div, reverse):
+        """sequential recurrence along each row (the exact arithmetic the scan kernel re-associates)"""
+        y = c.numpy().copy()
+        an = a.numpy()
+        if div is not None:
+            y = y / div.numpy()
+        n = y.shape[1]
+        idx = range(n - 1, -1, -1) if reverse else range(n)
+        prev = np.zeros(y.shape[0])
+        for i in idx:
+            prev = an[:, i] * prev + y[:, i]
+            y[:, i] = prev
+        return torch.from_numpy(y)
+
     def sumsq(self, r):
         v = self.O.l2(self._n(r))
         return v * v
