@@ -105,6 +105,33 @@ def test_plane_fused_relax_matches_four_pass_order(K, oracle, monkeypatch, shape
         assert np.array_equal(got, want), (shape, frun, ud, np.max(np.abs(got - want)))
 
 
+@pytest.mark.parametrize("shape", [(20, 16, 5), (9, 7, 4), (70, 18, 6), (11, 3, 7), (12, 9, 2)], ids=str)
+def test_partial_row_class_passes_compose_to_the_full_pass(shape):
+    """cedar_amd_relax3_pass_part: interior rows (part 1) then shell rows (part 2) of a row class equal the
+    whole class (part 0) bit for bit, for every class and both i-colour orders, odd and even extents and
+    grids too thin to have an interior -- the split the multi-GPU driver overlaps halo exchanges with"""
+    import ctypes as C
+    from cedar_amd import capi
+    import problems as pb
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    so = pb.random_op(g, 14, 51, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 52, -1, 1), pb.uniform(g, 53, -1, 1)
+    sor = np.zeros((2,) + g)
+    capi.Kernels().setup_recip3(so, sor)
+    u = C.c_uint
+    f = capi.lib.cedar_amd_relax3_pass_part
+    for jb in (0, 1):
+        for kb in (0, 1):
+            for efirst in (0, 1):
+                whole, parts = q0.copy(), q0.copy()
+                f(capi._p(so), capi._p(qf), capi._p(whole), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), jb, kb, efirst, 0)
+                for part in (1, 2):
+                    f(capi._p(so), capi._p(qf), capi._p(parts), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), jb, kb, efirst, part)
+                assert np.array_equal(whole, parts), (shape, jb, kb, efirst)
+                assert not np.array_equal(whole, q0) or ((ny - jb + 1) // 2 == 0 or (nz - kb + 1) // 2 == 0)
+
+
 def test_device_pointers_are_used_in_place(K):
     """the same entry points accept HBM pointers (no staging): results identical"""
     from cedar_amd import capi
