@@ -160,8 +160,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     nd, n_default, relax, bytes_per_dof, launches, label = WORKLOADS[args.workload]
     relax_kernel = "relax27_plane" if nd == 3 else relax
-    if world > 1:  # domain-decomposed runs exchange halos after every row class: four launches per sweep
+    if world > 4:  # rank grids with a y split exchange halos after every row class: four launches per sweep
         launches, relax_kernel = 4, "relax27_rows"
+    # (2 and 4 GPUs run z slabs: a whole k-parity -- the plane-fused kernel -- between two exchanges)
     n = args.size or n_default
 
     if world > 1:
@@ -189,7 +190,8 @@ def main():
     dof = float(n) ** nd
     dsolver, t_setup = None, None
     if world > 1:
-        # domain decomposition: one 512^3 block per GPU of a (px,py,pz)*512 global grid, halo over RCCL
+        # domain decomposition: one 512^3 block per GPU of a (px,py,pz)*512 global grid (z slabs up to 4 GPUs,
+        # 2x2x2 on 8 = BASELINE config 5), halo over RCCL
         if args.workload != "3d27":
             raise SystemExit("bench.py: multi-GPU runs are defined for the 3D 27-pt workload (BASELINE config 5)")
         import torch
@@ -266,7 +268,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if n == n_default:  # the PMC passes were taken at the benchmark size
-            traffic = pmc.get(args.workload + ("_rows" if world > 1 else ""), {}).get("hbm_bytes_per_launch")
+            traffic = pmc.get(args.workload + ("_rows" if world > 4 else ""), {}).get("hbm_bytes_per_launch")
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "relax sweep level 0 (%s)" % relax_kernel,

@@ -422,6 +422,14 @@ void cedar_amd_affine_lines(real_t *y, const real_t *a, const real_t *div, int n
 	affine_lines(y, a, div, nlines, n, ld, reverse, current_stream());
 }
 
+void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                             int kb, int up, int part)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_planes27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, kb, up, part, current_stream());
+}
+
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb)
 {

@@ -52,6 +52,8 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, size_t KK, hipStream_t st);
 void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int KK, int nstncl, int updown, hipStream_t st);
+void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                     int II, int JJ, int KK, int kb, int up, int part, hipStream_t st);
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                    int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part = 0);
 void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                      real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                     int II, int JJ, int KK, int jbF, int kb, int nrk, int frun, int nrun)
+                                                     int II, int JJ, int KK, int jbF, int kb, int nrk, int frun, int nrun,
+                                                     int kr0)
 {
 	__shared__ real_t xch[2][BS + 2];
 	const unsigned nblk = (unsigned)nrk * (unsigned)nrun;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ s
 	const int nF = (JJ - 2 - jbF + 1) / 2, nS = (JJ - 2 - (1 - jbF) + 1) / 2;
 	const int f0 = run * frun, f1 = min(nF, f0 + frun);
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
-	const size_t plane = (size_t)(1 + kb + 2 * kr) * sk;
+	const size_t plane = (size_t)(1 + kb + 2 * (kr + kr0)) * sk; // planes kr0 .. kr0+nrk-1 of parity kb
 	int t = 0;
 	for (int f = f0; f < f1; f++) {
 		// F row f: j = 1 + jbF + 2 f
@@ -492,22 +493,23 @@ static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t 
 // one launch, the S rows between two workgroups' runs in a second small one (see relax27_plane)
 template <int BS>
 static void launch_plane(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                         int II, int JJ, int KK, int jbF, int kb, int frun, hipStream_t st)
+                         int II, int JJ, int KK, int jbF, int kb, int frun, hipStream_t st, int kr0 = 0, int nrk_sub = -1)
 {
-	const int nF = (JJ - 2 - jbF + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	const int nF = (JJ - 2 - jbF + 1) / 2;
+	const int nrk = nrk_sub >= 0 ? nrk_sub : (KK - 2 - kb + 1) / 2;
 	if (nrk <= 0) return;
 	const int nrun = (nF + frun - 1) / frun;
 	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
 	const unsigned grid = xcd_grid((unsigned)nrk * (unsigned)nrun);
 	if (efirst) {
-		if (nt) hipLaunchKernelGGL((relax27_plane<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
-		else hipLaunchKernelGGL((relax27_plane<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
+		if (nt) hipLaunchKernelGGL((relax27_plane<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
+		else hipLaunchKernelGGL((relax27_plane<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
 	} else {
-		if (nt) hipLaunchKernelGGL((relax27_plane<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
-		else hipLaunchKernelGGL((relax27_plane<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun);
+		if (nt) hipLaunchKernelGGL((relax27_plane<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
+		else hipLaunchKernelGGL((relax27_plane<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
 	}
 	// S rows between runs: jbF = 0: j = 2 frun (r+1); jbF = 1: j = 1 + 2 frun (r+1), r = 0 .. nrun-2
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st);
+	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st, kr0);
 }
 
 // F rows per workgroup of the plane-fused pass; 0 = four launches per sweep (one per row class).
@@ -610,6 +612,59 @@ void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t 
 {
 	size_t n = (size_t)((II - 2 + 1) / 2) * (JJ - 2) * (KK - 2);
 	hipLaunchKernelGGL(relax7_colour, dim3(cap_grid(n, 256)), dim3(256), 0, st, so, qf, q, sor, II, JJ, KK, pts);
+}
+
+// Both row classes of the planes of parity kb, in sweep order (UP: j-parity 0 rows first, even i first;
+// DOWN the reverse): what a slab-decomposed run (rank grid 1 x 1 x pz) does between two halo exchanges --
+// the second row class needs nothing from another rank.  part: 0 all planes of the parity, 1 = those
+// with both k-neighbours owned (they read no ghost plane), 2 = the first / last owned plane.
+template <int BS>
+static void planes_bs(bool up, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                      int II, int JJ, int KK, int kb, int kr0, int nrk, hipStream_t st)
+{
+	if (nrk <= 0) return;
+	const int jbF = up ? 0 : 1;
+	const int frun = plane_frun(JJ);
+	if (frun > 0) {
+		launch_plane<BS>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st, kr0, nrk);
+		return;
+	}
+	for (int c = 0; c < 2; c++) {
+		const int jb = c == 0 ? jbF : 1 - jbF;
+		launch_rows_at<BS>(up, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, (JJ - 2 - jb + 1) / 2, kb, nrk, st, kr0);
+	}
+}
+
+void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                     int II, int JJ, int KK, int kb, int up, int part, hipStream_t st)
+{
+	const int nrk = (KK - 2 - kb + 1) / 2;
+	if (II < 3 || JJ < 3 || nrk <= 0) return;
+	const int npairs = (II - 2 + 1) / 2;
+	const int klo = kb == 0 ? 1 : 0;
+	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2) ? nrk - 1 : nrk;
+	const int nki = khi - klo > 0 ? khi - klo : 0;
+	// (kr0, count) pieces of the requested part
+	int pieces[2][2] = { { 0, nrk }, { 0, 0 } };
+	if (part == 1) { pieces[0][0] = klo; pieces[0][1] = nki; }
+	else if (part == 2 && nki > 0) { pieces[0][0] = 0; pieces[0][1] = klo; pieces[1][0] = khi; pieces[1][1] = nrk - khi; }
+	for (auto &pc : pieces) {
+		if (pc[1] <= 0) continue;
+		if (npairs <= 64) planes_bs<64>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (npairs <= 128) planes_bs<128>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (npairs <= 256) planes_bs<256>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (npairs <= 512) planes_bs<512>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (part != 1) { // rows too long for the row kernels: whole colours, everything with the shell
+			for (int c = 0; c < 4; c++) {
+				const int jb = (c >> 1) == 0 ? (up ? 0 : 1) : (up ? 1 : 0), ib = (c & 1) == 0 ? (up ? 0 : 1) : (up ? 1 : 0);
+				int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2;
+				if (ni <= 0 || nj <= 0) continue;
+				hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nrk, 256)), dim3(256), 0, st,
+				                   so, qf, q, sor, II, JJ, KK, ib, jb, kb);
+			}
+			break;
+		}
+	}
 }
 
 void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,

@@ -53,9 +53,11 @@ DOWN, UP = 0, 1
 
 # ------------------------------------------------------------------ topology
 def rank_grid(world):
-    """1 -> 1x1x1, 2 -> 1x1x2, 4 -> 1x2x2, 8 -> 2x2x2; otherwise the most cubic factorisation with
-    pz >= py >= px.  z is split first: z faces are contiguous in memory, and as long as x is not split
-    the fused row pass needs no x-face exchange + column fix-up between its two i-colours."""
+    """1 -> 1x1x1, 2 -> 1x1x2, 4 -> 1x1x4 (z slabs: two contiguous faces per rank, and a whole k-parity of
+    planes -- both row classes, the plane-fused kernel -- between two exchanges), 8 -> 2x2x2 (BASELINE
+    config 5); otherwise the most cubic factorisation with pz >= py >= px."""
+    if world <= 4:
+        return (1, 1, world)
     best = None
     for pz in range(1, world + 1):
         if world % pz:
@@ -263,6 +265,9 @@ class GpuBackend:
     def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0):
         self.lib.cedar_amd_relax3_pass_part(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x),
                                             jb, kb, int(efirst), part)
+
+    def relax_planes(self, A, b, x, sor, kb, up, part=0):
+        self.lib.cedar_amd_relax3_planes(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), kb, int(up), part)
 
     class _Side:
         """`with backend.side() as h:` issues the enclosed work (library launches and collectives) on a
@@ -543,6 +548,24 @@ class DistSolver3:
                     L.halo.exchange(x)
                 continue
             up = updown == UP
+            if t.p[0] == 1 and t.p[1] == 1:
+                # slab decomposition: the second row class of a plane needs nothing from another rank, so the
+                # unit between two exchanges is a whole k-parity (plane-fused kernel on big levels); its
+                # planes next to a ghost plane wait for the previous parity's halo, the others do not
+                for c in range(2):
+                    kb = c if up else 1 - c
+                    if L.overlap:
+                        be.relax_planes(L.A, b, x, L.sor, kb, up, 1)
+                        if pending is not None:
+                            be.wait(pending)
+                            pending = None
+                        be.relax_planes(L.A, b, x, L.sor, kb, up, 2)
+                        with be.side() as pending:
+                            L.halo.exchange(x)
+                    else:
+                        be.relax_planes(L.A, b, x, L.sor, kb, up)
+                        L.halo.exchange(x)
+                continue
             for c in range(4):
                 cc = c if up else 3 - c
                 jb, kb = cc & 1, cc >> 1

@@ -151,6 +151,11 @@ void cedar_amd_relax3_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t
  * part 2 = the remaining shell, part 0 = all.  Rows of a class do not couple: 1 then 2 equals 0. */
 void cedar_amd_relax3_pass_part(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                                 int jb, int kb, int efirst, int part);
+/* both row classes of the planes of k-parity kb in sweep order (up != 0: the UP order): the unit between two
+ * halo exchanges on a slab decomposition (rank grid 1 x 1 x pz), run with the plane-fused kernel on big
+ * levels.  part: 0 = all planes of the parity, 1 = planes whose k-neighbours are both owned, 2 = the others. */
+void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
+                             int kb, int up, int part);
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb);

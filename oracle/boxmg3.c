@@ -126,7 +126,8 @@ void orc3_relax_colour_part(const real_t *so, const real_t *qf, real_t *q, const
 	for (int k = 2 + ((pts - 1) / 4) % 2; k <= K1; k += 2)
 		for (int j = 2 + ((pts - 1) / 2) % 2; j <= J1; j += 2) {
 			const int inner = j >= 3 && j <= J1 - 1 && k >= 3 && k <= K1 - 1;
-			if ((part == 1 && !inner) || (part == 2 && inner)) continue;
+			const int kinner = k >= 3 && k <= K1 - 1; /* parts 3 / 4: planes with both k-neighbours owned / the others */
+			if ((part == 1 && !inner) || (part == 2 && inner) || (part == 3 && !kinner) || (part == 4 && kinner)) continue;
 			for (int i = 2 + (pts - 1) % 2; i <= I1; i += 2)
 				Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
 		}

@@ -27,6 +27,13 @@ class CpuBackend:
         for ib in ((0, 1) if efirst else (1, 0)):
             self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, part)
 
+    def relax_planes(self, A, b, x, sor, kb, up, part=0):
+        # cedar_amd_relax3_planes: both row classes of the planes of parity kb in sweep order
+        opart = {0: 0, 1: 3, 2: 4}[part]
+        for jb in ((0, 1) if up else (1, 0)):
+            for ib in ((0, 1) if up else (1, 0)):
+                self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, opart)
+
     class _Side:  # CPU: no streams, the "side" work simply runs in program order
         def __enter__(self):
             return self

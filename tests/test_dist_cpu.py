@@ -84,6 +84,8 @@ CASES = [
     ("rand27", (8, 8, 8), (2, 2, 2), 32),
     ("rand27", (6, 8, 8), (1, 2, 2), 2),
     ("rand27", (10, 12, 16), (1, 1, 2), 4),
+    ("rand27", (9, 7, 8), (1, 1, 4), 2),
+    ("fe27", (8, 8, 8), (1, 1, 4), 4),
 ]
 
 
@@ -116,7 +118,7 @@ def test_distributed_equals_single_domain(case, tmp_path, oracle):
 def test_rank_grid_and_neighbours():
     from cedar_amd.dist import Topology, rank_grid
     assert rank_grid(1) == (1, 1, 1) and rank_grid(2) == (1, 1, 2)
-    assert rank_grid(4) == (1, 2, 2) and rank_grid(8) == (2, 2, 2) and rank_grid(12) == (2, 2, 3)
+    assert rank_grid(4) == (1, 1, 4) and rank_grid(8) == (2, 2, 2) and rank_grid(12) == (2, 2, 3)
     t = Topology(5, 8)  # coord (1,0,1): rank = k*4 + j*2 + i (src/3d/util/topo.cc:82-84)
     assert t.coord == (1, 0, 1)
     nb = t.neighbours()

@@ -132,6 +132,37 @@ def test_partial_row_class_passes_compose_to_the_full_pass(shape):
                 assert not np.array_equal(whole, q0) or ((ny - jb + 1) // 2 == 0 or (nz - kb + 1) // 2 == 0)
 
 
+@pytest.mark.parametrize("frun", [0, 1, 3])
+@pytest.mark.parametrize("shape", [(20, 16, 6), (9, 17, 5), (70, 18, 4), (11, 33, 7)], ids=str)
+def test_plane_parity_passes_compose_to_the_sweep(K, oracle, monkeypatch, shape, frun):
+    """cedar_amd_relax3_planes (the unit of a slab-decomposed run): the two k-parities in sweep order equal
+    the full sweep, interior planes + shell planes equal the whole parity; with and without the plane-fused
+    kernel (CEDAR_AMD_FRUN), both directions; against the oracle bit for bit"""
+    import ctypes as C
+    from cedar_amd import capi
+    import problems as pb
+    monkeypatch.setenv("CEDAR_AMD_FRUN", str(frun))
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    so = pb.random_op(g, 14, 61, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 62, -1, 1), pb.uniform(g, 63, -1, 1)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip3(so, sor)
+    u = C.c_uint
+    f = capi.lib.cedar_amd_relax3_planes
+    for up in (0, 1):
+        want = q0.copy()
+        oracle.relax3(so, qf, want, sor, up)
+        whole, parts = q0.copy(), q0.copy()
+        for c in range(2):
+            kb = c if up else 1 - c
+            f(capi._p(so), capi._p(qf), capi._p(whole), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), kb, up, 0)
+            for part in (1, 2):
+                f(capi._p(so), capi._p(qf), capi._p(parts), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), kb, up, part)
+        assert np.array_equal(whole, want), (shape, frun, up)
+        assert np.array_equal(parts, want), (shape, frun, up)
+
+
 def test_device_pointers_are_used_in_place(K):
     """the same entry points accept HBM pointers (no staging): results identical"""
     from cedar_amd import capi
