@@ -417,6 +417,22 @@ void cedar_amd_setup_interp2_phase(real_t *so, real_t *ci, len_t iif, len_t jjf,
 	setup_interp2_phase(sso.get(), sci.get(), (int)iif, (int)jjf, (int)iic, (int)jjc, ifd, phase, ilo, jlo, current_stream());
 }
 
+void cedar_amd_lines_rhs2(const real_t *so, const real_t *qf, const real_t *q, real_t *out, len_t ii, len_t jj,
+                          int nstncl, int dir, int lb)
+{
+	lines_rhs2(so, qf, q, out, (int)ii, (int)jj, nstncl, dir, lb, current_stream());
+}
+
+void cedar_amd_lines_carry(real_t *y, const real_t *p, const real_t *c, int nlines, int n, int ld)
+{
+	lines_carry(y, p, c, nlines, n, ld, current_stream());
+}
+
+void cedar_amd_lines_store2(const real_t *in, real_t *q, len_t ii, len_t jj, int dir, int lb)
+{
+	lines_store2(in, q, (int)ii, (int)jj, dir, lb, current_stream());
+}
+
 void cedar_amd_affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse)
 {
 	affine_lines(y, a, div, nlines, n, ld, reverse, current_stream());

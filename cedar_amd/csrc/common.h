@@ -77,6 +77,10 @@ void relax2_colour5(const real_t *so, const real_t *qf, real_t *q, const real_t 
                     int II, int JJ, int jo, hipStream_t st);
 void setup_interp2_phase(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, int phase,
                          int ilo, int jlo, hipStream_t st);
+void lines_rhs2(const real_t *so, const real_t *qf, const real_t *q, real_t *out, int II, int JJ, int nstncl, int dir, int lb,
+                hipStream_t st);
+void lines_store2(const real_t *in, real_t *q, int II, int JJ, int dir, int lb, hipStream_t st);
+void lines_carry(real_t *y, const real_t *p, const real_t *c, int nlines, int n, int ld, hipStream_t st);
 void affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse, hipStream_t st);
 // 2D periodic boundary conditions (periodic2d.hip); ipn = 1 per_y, 2 per_x, 3 per_xy
 void wrap2(real_t *q, int II, int JJ, int nplanes, int do_y, int do_x, hipStream_t st);

@@ -507,4 +507,78 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	if (ipn == 2) wrap2(q, II, JJ, 1, 0, 1, st);
 }
 
+// ---- pieces of the domain-decomposed line relaxation (cedar_amd/dist2d.py): right-hand sides of the
+// lines of one zebra colour into a line-contiguous buffer, the carry correction, and the way back.
+template <bool NINE>
+__global__ __launch_bounds__(256) void xlines_rhs_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                          const real_t *__restrict__ q, real_t *__restrict__ out,
+                                                          int II, int JJ, int lb, int ld)
+{
+	const int l = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x; // line of the colour, position
+	if (t >= II - 2) return;
+	const size_t sj = II, PS = (size_t)II * JJ;
+	const size_t x = (size_t)(1 + lb + 2 * l) * sj + 1 + t;
+	real_t s = qf[x]; // relax_lines_x.f90:106-111 / :128-129, reference term order
+	s = s + so[KS * PS + x] * q[x - sj];
+	s = s + so[KS * PS + x + sj] * q[x + sj];
+	if (NINE) {
+		s = s + so[KSW * PS + x] * q[x - 1 - sj];
+		s = s + so[KNW * PS + x + 1] * q[x + 1 - sj];
+		s = s + so[KNW * PS + x + sj] * q[x - 1 + sj];
+		s = s + so[KSW * PS + x + 1 + sj] * q[x + 1 + sj];
+	}
+	out[(size_t)l * ld + t] = s;
+}
+
+__global__ __launch_bounds__(256) void xlines_store_kernel(const real_t *__restrict__ in, real_t *__restrict__ q,
+                                                            int II, int lb, int ld)
+{
+	const int l = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= II - 2) return;
+	q[(size_t)(1 + lb + 2 * l) * II + 1 + t] = in[(size_t)l * ld + t];
+}
+
+// y[l][i] = y[l][i] + p[l][i] * c[l]: the carry entering a line segment times the running product of its multipliers
+__global__ __launch_bounds__(256) void lines_carry_kernel(real_t *__restrict__ y, const real_t *__restrict__ p,
+                                                           const real_t *__restrict__ c, int n, int ld)
+{
+	const int l = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const size_t x = (size_t)l * ld + t;
+	y[x] = y[x] + p[x] * c[l];
+}
+
+// dir 0: x lines (rows 1+lb, 3+lb, ..), dir 1: y lines (columns 1+lb, 3+lb, ..); out / in: (lines, positions), ld = positions
+void lines_rhs2(const real_t *so, const real_t *qf, const real_t *q, real_t *out, int II, int JJ, int nstncl, int dir, int lb,
+                hipStream_t st)
+{
+	const int nlines = dir == 0 ? (JJ - 2 - lb + 1) / 2 : (II - 2 - lb + 1) / 2;
+	const int n = dir == 0 ? II - 2 : JJ - 2;
+	if (nlines <= 0 || n <= 0) return;
+	if (dir == 0) {
+		dim3 grid((n + 255) / 256, nlines);
+		if (nstncl == 5) hipLaunchKernelGGL(xlines_rhs_kernel<true>, grid, dim3(256), 0, st, so, qf, q, out, II, JJ, lb, n);
+		else hipLaunchKernelGGL(xlines_rhs_kernel<false>, grid, dim3(256), 0, st, so, qf, q, out, II, JJ, lb, n);
+	} else {
+		dim3 tg((nlines + 31) / 32, (n + 31) / 32);
+		if (nstncl == 5) hipLaunchKernelGGL(ylines_rhs_T<true>, tg, dim3(256), 0, st, so, qf, q, out, II, JJ, lb, nlines, n, 0);
+		else hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, out, II, JJ, lb, nlines, n, 0);
+	}
+}
+
+void lines_store2(const real_t *in, real_t *q, int II, int JJ, int dir, int lb, hipStream_t st)
+{
+	const int nlines = dir == 0 ? (JJ - 2 - lb + 1) / 2 : (II - 2 - lb + 1) / 2;
+	const int n = dir == 0 ? II - 2 : JJ - 2;
+	if (nlines <= 0 || n <= 0) return;
+	if (dir == 0) hipLaunchKernelGGL(xlines_store_kernel, dim3((n + 255) / 256, nlines), dim3(256), 0, st, in, q, II, lb, n);
+	else hipLaunchKernelGGL(ylines_scatter_T, dim3((nlines + 31) / 32, (n + 31) / 32), dim3(256), 0, st, in, q, II, JJ, lb, nlines, n, 0);
+}
+
+void lines_carry(real_t *y, const real_t *p, const real_t *c, int nlines, int n, int ld, hipStream_t st)
+{
+	if (nlines <= 0 || n <= 0) return;
+	hipLaunchKernelGGL(lines_carry_kernel, dim3((n + 255) / 256, nlines), dim3(256), 0, st, y, p, c, n, ld);
+}
+
 } // namespace cedar_amd

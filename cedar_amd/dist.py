@@ -419,6 +419,23 @@ class GpuBackend:
                                         nl, n, n, int(bool(reverse)))
         return y
 
+    def lines_rhs2(self, A, b, x, d, lb):
+        """(lines of colour lb, positions): b - (off-line part of A) x, computed by the library"""
+        JJ, II = x.shape
+        nl = ((JJ - 2 - lb + 1) // 2) if d == 0 else ((II - 2 - lb + 1) // 2)
+        n = II - 2 if d == 0 else JJ - 2
+        out = torch.empty((nl, n), dtype=torch.float64, device=self.device)
+        self.lib.cedar_amd_lines_rhs2(self._p(A), self._p(b), self._p(x), self._p(out), *self._dims2(x), A.shape[0], d, lb)
+        return out
+
+    def lines_carry(self, y, p, c):
+        nl, n = y.shape
+        self.lib.cedar_amd_lines_carry(self._p(y), self._p(p), self._p(c.contiguous()), nl, n, n)
+        return y
+
+    def lines_store2(self, xs, x, d, lb):
+        self.lib.cedar_amd_lines_store2(self._p(xs.contiguous()), self._p(x), *self._dims2(x), d, lb)
+
     def box_copy(self, arr, nplanes, nboxes, boxes, offs, buf, unpack):
         KK, JJ, II = arr.shape[-3:]
         self.lib.cedar_amd_box_copy(self._p(arr), C.c_uint(II), C.c_uint(JJ), C.c_uint(KK), nplanes, nboxes,

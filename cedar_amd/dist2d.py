@@ -368,6 +368,7 @@ class DistLines:
         dist.all_gather(parts, src, group=self.group)
         return [p.to(v.device) for p in parts] if staged else parts
 
+    # _rhs / _store: the same pieces in plain tensor operations for back ends without the library (CPU tests)
     def _rhs(self, x, b, lb):
         """right-hand sides of the lines of colour lb (0-based interior parity): b - (off-line part of A) x,
         reference term order (relax_lines_x.f90:104-109 / relax_lines_y.f90:103-107); -> (lines, positions)"""
@@ -414,7 +415,7 @@ class DistLines:
             if self.dp[sel].shape[0] == 0:
                 halo.exchange(v3(x))
                 continue
-            rhs = self._rhs(x, b, lb)
+            rhs = be.lines_rhs2(self.A, b, x, self.d, lb) if hasattr(be, "lines_rhs2") else self._rhs(x, b, lb)
             dp, es, en, pf, pb = (v[sel].contiguous() for v in (self.dp, self.es, self.e_next, self.pf, self.pb))
             # forward sweep from a zero carry, then the carry entering this segment
             y = be.affine_lines(rhs, -es, None, False)
@@ -423,7 +424,7 @@ class DistLines:
             for r in range(self.seg):                      # compose the segments to the left
                 y_in = parts[r][:, 0] + parts[r][:, 1] * y_in
             if self.seg > 0:
-                y = y + pf * y_in[:, None]
+                y = be.lines_carry(y, pf, y_in) if hasattr(be, "lines_carry") else y + pf * y_in[:, None]
             # backward sweep from a zero carry, then the carry entering from the right
             xs = be.affine_lines(y, -en, dp, True)
             parts = self._gather(torch.stack([xs[:, 0], pb[:, 0]], dim=1))
@@ -431,6 +432,9 @@ class DistLines:
             for r in range(self.nseg - 1, self.seg, -1):
                 x_in = parts[r][:, 0] + parts[r][:, 1] * x_in
             if self.seg < self.nseg - 1:
-                xs = xs + pb * x_in[:, None]
-            self._store(x, xs, lb)
+                xs = be.lines_carry(xs, pb, x_in) if hasattr(be, "lines_carry") else xs + pb * x_in[:, None]
+            if hasattr(be, "lines_store2"):
+                be.lines_store2(xs, x, self.d, lb)
+            else:
+                self._store(x, xs, lb)
             halo.exchange(v3(x))

@@ -182,6 +182,14 @@ void cedar_amd_setup_interp2_phase(real_t *so, real_t *ci, len_t iif, len_t jjf,
  * from a zero carry, c_i = y_i on entry (divided by div_i when div != NULL).  The two sweeps of DPTTRS per
  * line segment for the domain-decomposed line relaxation (src/2d/ftn/mpi/BMG2_SymStd_relax_lines_x.f90). */
 void cedar_amd_affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int n, int ld, int reverse);
+/* around it (device pointers): right-hand sides b - (off-line part of A) x of the lines of zebra colour lb
+ * (0-based interior parity) in direction dir (0 = x lines, 1 = y lines) into out[line][position]
+ * (relax_lines_x.f90:104-109, relax_lines_y.f90:103-107); y[l][i] += p[l][i] * c[l] (the carry entering a
+ * segment times the running product of its multipliers); and the solved lines back into q */
+void cedar_amd_lines_rhs2(const real_t *so, const real_t *qf, const real_t *q, real_t *out, len_t ii, len_t jj,
+                          int nstncl, int dir, int lb);
+void cedar_amd_lines_carry(real_t *y, const real_t *p, const real_t *c, int nlines, int n, int ld);
+void cedar_amd_lines_store2(const real_t *in, real_t *q, len_t ii, len_t jj, int dir, int lb);
 /* pack (unpack = 0) / unpack (1) up to 26 sub-boxes of a device array (nplanes x kk x jj x ii) to /
  * from one contiguous device buffer in one launch: boxes = {i0,j0,k0,ni,nj,nk} per box (0-based incl.
  * ghost), offsets[b] = start of box b in the buffer in doubles per plane (box b occupies
