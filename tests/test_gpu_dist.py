@@ -62,9 +62,11 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
 # small grids on the in-order path, which the first two cases keep covering)
 @pytest.mark.parametrize("n,pgrid,overlap_min", [((16, 12, 10), (2, 1, 1), 96), ((8, 8, 8), (2, 2, 1), 96),
                                                  ((12, 10, 16), (1, 1, 2), 4), ((8, 8, 8), (1, 2, 2), 4),
-                                                 ((8, 8, 8), (2, 2, 1), 4), ((64, 64, 64), (1, 1, 2), 16), ((20, 16, 8), (1, 1, 4), 4)],
+                                                 ((8, 8, 8), (2, 2, 1), 4), ((64, 64, 64), (1, 1, 2), 16), ((20, 16, 8), (1, 1, 4), 4),
+                                                 # 320 rows: the slab path runs the plane-fused kernel on level 0
+                                                 ((12, 320, 8), (1, 1, 2), 4)],
                          ids=["2ranks-x", "4ranks-xy", "2ranks-z-overlap", "4ranks-yz-overlap", "4ranks-xy-overlap",
-                              "2ranks-z-64cubed-overlap", "4ranks-z-slabs-overlap"])
+                              "2ranks-z-64cubed-overlap", "4ranks-z-slabs-overlap", "2ranks-z-plane-fused"])
 def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, oracle):
     import problems as pb
     world = pgrid[0] * pgrid[1] * pgrid[2]
