@@ -160,7 +160,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     nd, n_default, relax, bytes_per_dof, launches, label = WORKLOADS[args.workload]
     relax_kernel = "relax27_plane" if nd == 3 else relax
-    if world > 4:  # rank grids with a y split exchange halos after every row class: four launches per sweep
+    if world > 4 and nd == 3:  # rank grids with a y split exchange halos after every row class: four launches per sweep
         launches, relax_kernel = 4, "relax27_rows"
     # (2 and 4 GPUs run z slabs: a whole k-parity -- the plane-fused kernel -- between two exchanges)
     n = args.size or n_default
@@ -192,20 +192,38 @@ def main():
     if world > 1:
         # domain decomposition: one 512^3 block per GPU of a (px,py,pz)*512 global grid (z slabs up to 4 GPUs,
         # 2x2x2 on 8 = BASELINE config 5), halo over RCCL
-        if args.workload != "3d27":
-            raise SystemExit("bench.py: multi-GPU runs are defined for the 3D 27-pt workload (BASELINE config 5)")
         import torch
         from cedar_amd.dist import DistSolver3, GpuBackend, Topology
         dev = torch.device("cuda", local_rank)
-        topo = Topology(rank, world)
-        g = (n + 2, n + 2, n + 2)
-        A = torch.zeros((14,) + g, dtype=torch.float64, device=dev)
-        bt = torch.zeros(g, dtype=torch.float64, device=dev)
-        import ctypes as C
-        place = [float(topo.coord[d] * n) for d in range(3)] + [float(n * topo.p[d]) for d in range(3)]
-        pp = (C.c_double * 6)(*place)
-        capi.lib.cedar_amd_gallery(112, A.data_ptr(), bt.data_ptr(), n, n, n, pp)  # fe3 placed in the global grid
-        dsolver = DistSolver3(GpuBackend(dev), topo, A)
+        if nd == 3:
+            topo = Topology(rank, world)
+            g = (n + 2, n + 2, n + 2)
+            A = torch.zeros((14,) + g, dtype=torch.float64, device=dev)
+            bt = torch.zeros(g, dtype=torch.float64, device=dev)
+            import ctypes as C
+            place = [float(topo.coord[d] * n) for d in range(3)] + [float(n * topo.p[d]) for d in range(3)]
+            pp = (C.c_double * 6)(*place)
+            capi.lib.cedar_amd_gallery(112, A.data_ptr(), bt.data_ptr(), n, n, n, pp)  # fe3 placed in the global grid
+            dsolver = DistSolver3(GpuBackend(dev), topo, A)
+        else:
+            # 2D workloads: n^2 per GPU of a (px n) x (py n) global grid, cedar_amd/dist2d.py.  The
+            # synthetic operators are host generators of the whole grid: every rank builds it and keeps its block.
+            import problems as pb
+            from cedar_amd.dist2d import DistSolver2, rank_grid2
+            px, py = rank_grid2(world)
+            if 5.0 * (px * n + 2) * (py * n + 2) * 8 > 12e9:
+                raise SystemExit("bench.py: the host generator of this 2D workload is too large for %d GPUs at %d^2 per GPU; "
+                                 "use --size" % (world, n))
+            topo = Topology(rank, world, (px, py, 1))
+            gso = {"2d9": pb.varcoef9, "2d9l": pb.aniso9, "2d5": pb.poisson2}[args.workload](px * n, py * n)
+            gb = pb.rhs2(px * n, py * n)
+            ci, cj = topo.coord[:2]
+            sl = (slice(cj * n, cj * n + n + 2), slice(ci * n, ci * n + n + 2))
+            m = pb.interior_mask((n + 2, n + 2)).astype(np.float64)
+            A = torch.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m).to(dev)
+            bt = torch.from_numpy(np.ascontiguousarray(gb[sl]) * m).to(dev)
+            del gso, gb
+            dsolver = DistSolver2(GpuBackend(dev), topo, A, relax=relax)
         xt = torch.zeros_like(bt)
         so = b = x = None
 
@@ -293,8 +311,8 @@ def main():
                        "grid_per_gpu": [n] * nd, "levels": solver.nlevels(), "cycle": "V(2,1)",
                        "relaxation": relax,
                        "parallelism": "single GPU" if world == 1 else
-                       "domain decomposition %s ranks, %d^3 per GPU, halo exchange over %s" %
-                       ("x".join(map(str, topo.p)), n, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
+                       "domain decomposition %s ranks, %d^%d per GPU, halo exchange over %s" %
+                       ("x".join(map(str, topo.p[:nd])), n, nd, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
             "roofline": roofline,
             "setup_ms": None if t_setup is None else t_setup * 1e3,  # device-side interp + Galerkin + relax set-up
         }
