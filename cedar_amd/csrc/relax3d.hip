@@ -514,7 +514,7 @@ static void launch_plane(bool efirst, const real_t *so, const real_t *qf, real_t
 
 // F rows per workgroup of the plane-fused pass; 0 = four launches per sweep (one per row class).
 // Measured on MI355X (profiles/r01_experiment_plane_fused_relax.log): 512^3 -3..-7.5 % for runs of
-// 16..64 rows, 384^3 -11 % at 16, 256^3 and below +3..+11 % (the whole level sits closer to the
+// 8..64 rows, 448^3 -9 % and 384^3 -11 % at 8..16, 320^3 -5 % at 8, 256^3 and below +3..+11 % (the whole level sits closer to the
 // Infinity Cache and the four-launch order already re-reads from it) => fused only on big levels.
 // CEDAR_AMD_FRUN overrides (0 = never; n = runs of n rows wherever a plane has >= 4 runs).
 static int plane_frun(int JJ)
@@ -525,9 +525,7 @@ static int plane_frun(int JJ)
 		const int frun = atoi(e);
 		return (frun <= 0 || ny < 4 * frun) ? 0 : frun;
 	}
-	if (ny >= 448) return 32;
-	if (ny >= 320) return 16;
-	return 0;
+	return ny >= 320 ? 8 : 0; // runs of 8 rows: within 1 % of the best run length at 320, 384, 448 and 512
 }
 
 // one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs exchange halos
