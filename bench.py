@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     # name: (nd, default n, relax, algorithmic B/DOF of one level-0 relax sweep, launches per sweep, label)
     # 27-pt: the sweep is two plane-fused launches (relax27_plane: the planes of one k-parity, both row
-    # classes) plus two launches over the few rows between workgroup runs (<1 % of the rows)
+    # classes) plus two small launches over the S rows between workgroup runs (one S row in eight)
     "3d27": (3, 512, "point", 136.0, 2, "3D 27-pt gallery::fe Poisson-type, {n}^3, 8-colour GS V(2,1)"),
     "2d9": (2, 4096, "point", 64.0, 2, "2D 9-pt variable-coefficient, {n}^2, 4-colour GS V(2,1)"),
     "2d9l": (2, 8192, "line-xy", 128.0, 8, "2D 9-pt anisotropic eps=1e-4, {n}^2, zebra line relax x+y V(2,1)"),
