@@ -208,6 +208,8 @@ public:
 		st.cycle = settings.cycle;
 		if (settings.relaxation != ml_settings::relax_type::point)
 			log::error << "3D: only point relaxation is implemented on the GPU path" << std::endl;
+		if (kman->get_params()->per_mask() != 0)
+			log::error << "3D: periodic boundaries are not implemented on the GPU path (2D only); solving the Dirichlet problem" << std::endl;
 		h = cedar_amd_solver_create(3, fop.shape(0), fop.shape(1), fop.shape(2), stencil_ndirs<fsten>::value, fop.data(), 0, &st);
 	}
 	~solver() { cedar_amd_solver_destroy(h); }
