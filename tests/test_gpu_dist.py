@@ -64,9 +64,12 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
                                                  ((12, 10, 16), (1, 1, 2), 4), ((8, 8, 8), (1, 2, 2), 4),
                                                  ((8, 8, 8), (2, 2, 1), 4), ((64, 64, 64), (1, 1, 2), 16), ((20, 16, 8), (1, 1, 4), 4),
                                                  # 320 rows: the slab path runs the plane-fused kernel on level 0
-                                                 ((12, 320, 8), (1, 1, 2), 4)],
+                                                 ((12, 320, 8), (1, 1, 2), 4),
+                                                 # 6.5e6 unknowns: plane-fused level 0 under a halo in flight, three
+                                                 # distributed levels, gathered 16x80x80 coarse problem
+                                                 ((64, 320, 160), (1, 1, 2), 32)],
                          ids=["2ranks-x", "4ranks-xy", "2ranks-z-overlap", "4ranks-yz-overlap", "4ranks-xy-overlap",
-                              "2ranks-z-64cubed-overlap", "4ranks-z-slabs-overlap", "2ranks-z-plane-fused"])
+                              "2ranks-z-64cubed-overlap", "4ranks-z-slabs-overlap", "2ranks-z-plane-fused", "2ranks-z-6M-unknowns"])
 def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, oracle):
     import problems as pb
     world = pgrid[0] * pgrid[1] * pgrid[2]
