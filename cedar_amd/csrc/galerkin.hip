@@ -208,6 +208,10 @@ void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF
 	// is the readable statement of the same sum and stays selectable for cross-checks
 	static const bool generic = getenv("CEDAR_AMD_GALERKIN_GENERIC") && atoi(getenv("CEDAR_AMD_GALERKIN_GENERIC")) != 0;
 	if (!generic) {
+		// CEDAR_AMD_GALERKIN_TWOSTAGE=1 selects the experimental two-stage product (galerkin3_twostage.hip: same
+		// coarse operators bit for bit, measured slower than the one-stage kernels -- profiles/r01_experiment_galerkin_twostage.log)
+		const char *e2 = getenv("CEDAR_AMD_GALERKIN_TWOSTAGE");
+		if (e2 && atoi(e2) == 1 && galerkin3_twostage(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
 		galerkin3_part0(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
 		galerkin3_part1(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
 		galerkin3_part2(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);

@@ -202,3 +202,24 @@ def test_unserved_boundary_codes_are_refused_loudly(K, capfd):
                                   0, 14, 2, 1, 0, 8)
     assert np.array_equal(q3, q30)
     assert "Dirichlet" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("shape,nst", [((9, 8, 7), 14), ((13, 9, 10), 4), ((33, 20, 17), 14), ((17, 12, 31), 4)], ids=str)
+def test_two_stage_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeypatch, shape, nst):
+    """the opt-in two-stage product (galerkin3_twostage.hip) keeps the one-stage kernels' summation order: same
+    coarse operator bit for bit, with the whole grid in one slab and with slabs of 4 coarse planes"""
+    import problems as pb
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    gc = pb.coarse_shape(g)
+    so = pb.random_op(g, nst, 5, zero_ghost=False)
+    ci = pb.uniform((26,) + gc, 6, -1, 1)
+    out = []
+    for ts, mb in (("0", "2048"), ("1", "2048"), ("1", "1")):
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_TWOSTAGE", ts)
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_SCRATCH_MB", mb)
+        soc = np.zeros((14,) + gc)
+        K.galerkin3(so, soc, ci)
+        out.append(soc)
+    assert np.any(out[0] != 0)
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
