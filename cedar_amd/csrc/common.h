@@ -131,6 +131,11 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
 size_t ylines_scratch_doubles(int II, int JJ);
 void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *scratch,
                    int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0);
+// y-lines on transposed arrays (lines.hip): transposed operator planes, transposed right-hand side, scratch for q^T
+void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st);
+void setup_lines_yt(const real_t *so, real_t *sot, int II, int JJ, int nstncl, hipStream_t st);
+void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt, const real_t *sor,
+                    int II, int JJ, int nstncl, int updown, hipStream_t st);
 // cgsolve.hip
 void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
 void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);

@@ -32,6 +32,10 @@ struct Level {
 	real_t *x = nullptr, *b = nullptr, *res = nullptr;
 	real_t *SOR0 = nullptr, *SOR1 = nullptr;
 	real_t *yscr = nullptr; // y-line scratch
+	// y-lines on transposed arrays (Dirichlet; lines.hip relax_lines_yt): transposed operator planes, transposed
+	// right-hand side, scratch for the transposed x; bt_fresh: bt holds the transpose of this visit's b
+	real_t *At = nullptr, *bt = nullptr, *xt = nullptr;
+	mutable bool bt_fresh = false;
 };
 
 real_t *dalloc(size_t n)
@@ -80,7 +84,7 @@ int compute_num_levels(int nd, len_t nx, len_t ny, len_t nz, int min_coarse)
 	return ng;
 }
 
-void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, bool lines_y)
+void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, bool lines_y, bool lines_yt)
 {
 	L.nx = nx; L.ny = ny; L.nz = nd == 3 ? nz : 1;
 	L.II = nx + 2; L.JJ = ny + 2; L.KK = nd == 3 ? nz + 2 : 1;
@@ -91,6 +95,11 @@ void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, 
 	if (lines_y) {
 		L.SOR1 = dalloc(L.npts * 2);
 		L.yscr = dalloc(ylines_scratch_doubles(L.II, L.JJ));
+	}
+	if (lines_yt) {
+		L.At = dalloc(L.npts * nst);
+		L.bt = dalloc(L.npts);
+		L.xt = dalloc(L.npts);
 	}
 	if (coarse) {
 		L.A = dalloc(L.npts * nst);
@@ -104,6 +113,20 @@ void residual(const cedar_amd_solver *s, const Level &L, const real_t *x, const 
 {
 	if (s->nd == 2) residual2(L.A, b, x, r, L.II, L.JJ, L.nst, st);
 	else residual3(L.A, b, x, r, L.II, L.JJ, L.KK, L.nst, st);
+}
+
+// one y-line sweep: on the transposed arrays when the level keeps them
+void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int updown, int ipn, hipStream_t st)
+{
+	if (!L.At) {
+		relax_lines_y(L.A, b, x, sor, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn);
+		return;
+	}
+	if (!L.bt_fresh) {
+		transpose2(b, L.bt, L.II, L.JJ, st);
+		L.bt_fresh = true;
+	}
+	relax_lines_yt(L.At, L.bt, x, L.xt, sor, L.II, L.JJ, L.nst, updown, st);
 }
 
 void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *b, int updown, int n, hipStream_t st)
@@ -121,13 +144,13 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 		switch (s->st.relaxation) {
 		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
 		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn); break;
-		case CEDAR_AMD_RELAX_LINE_Y: relax_lines_y(L.A, b, x, L.SOR0, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn); break;
+		case CEDAR_AMD_RELAX_LINE_Y: lines_y(L, x, b, L.SOR0, updown, ipn, st); break;
 		default:
 			if (updown == BMG_DOWN) {
 				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn);
-				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn);
+				lines_y(L, x, b, L.SOR1, updown, ipn, st);
 			} else {
-				relax_lines_y(L.A, b, x, L.SOR1, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn);
+				lines_y(L, x, b, L.SOR1, updown, ipn, st);
 				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn);
 			}
 		}
@@ -145,6 +168,7 @@ void coarse_solve(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t s
 void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_t st)
 {
 	Level &L = s->lv[lvl], &K = s->lv[lvl + 1];
+	L.bt_fresh = false; // b of this visit has not been transposed yet
 	smooth(s, L, x, b, BMG_DOWN, s->st.nrelax_pre, st);
 	residual(s, L, x, b, L.res, st);
 	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
@@ -276,7 +300,11 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	}
 	s->lv.resize(nlev);
 	const bool ly = nd == 2 && (s->st.relaxation == CEDAR_AMD_RELAX_LINE_XY || s->st.relaxation == CEDAR_AMD_RELAX_LINE_Y);
-	level_init(s->lv[0], nd, (int)nx, (int)ny, (int)nz, nstencil, false, ly);
+	// y-lines run on transposed arrays unless periodic (the wraps and the cyclic closure stay on relax_lines_y);
+	// CEDAR_AMD_YLINES_TRANSPOSED=0 keeps the gather / solve / scatter pipeline for cross-checks
+	const char *eyt = getenv("CEDAR_AMD_YLINES_TRANSPOSED");
+	const bool lyt = ly && s->st.ibc == 0 && !(eyt && atoi(eyt) == 0);
+	level_init(s->lv[0], nd, (int)nx, (int)ny, (int)nz, nstencil, false, ly, lyt);
 	Level &F0 = s->lv[0];
 	if (own_device_so && is_device_ptr(so)) {
 		F0.A = const_cast<real_t *>(so);
@@ -290,7 +318,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		const Level &F = s->lv[l - 1];
 		int nxc = (int)((F.nx - 1) / 2. + 1), nyc = (int)((F.ny - 1) / 2. + 1);
 		int nzc = nd == 3 ? (int)((F.nz - 1) / 2. + 1) : 1;
-		level_init(s->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, true, ly);
+		level_init(s->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, true, ly, lyt);
 	}
 	const Level &C = s->lv.back();
 	// periodic: the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)
@@ -321,6 +349,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 				setup_lines_x(F.A, F.SOR0, F.II, F.JJ, st, s->st.ibc == 2 || s->st.ibc == 3);
 				setup_lines_y(F.A, F.SOR1, F.II, F.JJ, st, s->st.ibc == 1 || s->st.ibc == 3);
 			}
+			if (F.At) setup_lines_yt(F.A, F.At, F.II, F.JJ, F.nst, st);
 		} else {
 			int ifd = F.nst == 4;
 			setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
@@ -351,6 +380,7 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 		Level &L = s->lv[l];
 		if (L.ownA) (void)hipFree(L.A);
 		(void)hipFree(L.P); (void)hipFree(L.res); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.yscr);
+		(void)hipFree(L.At); (void)hipFree(L.bt); (void)hipFree(L.xt);
 		if (l > 0) { (void)hipFree(L.x); (void)hipFree(L.b); }
 	}
 	(void)hipFree(s->ABD); (void)hipFree(s->bbd); (void)hipFree(s->red); (void)hipFree(s->dinfo);
@@ -432,7 +462,10 @@ float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real
 	CEDAR_HIP_CHECK(hipEventCreate(&e0));
 	CEDAR_HIP_CHECK(hipEventCreate(&e1));
 	CEDAR_HIP_CHECK(hipEventRecord(e0, st));
-	for (int i = 0; i < n; i++) smooth(s, L, x_dev, b_dev, (i & 1) ? BMG_UP : BMG_DOWN, 1, st);
+	for (int i = 0; i < n; i++) {
+		L.bt_fresh = false; // every timed sweep pays for its own transpose of b (a V(2,1) visit pays two per three sweeps)
+		smooth(s, L, x_dev, b_dev, (i & 1) ? BMG_UP : BMG_DOWN, 1, st);
+	}
 	CEDAR_HIP_CHECK(hipEventRecord(e1, st));
 	CEDAR_HIP_CHECK(hipEventSynchronize(e1));
 	float ms = 0;

@@ -132,3 +132,25 @@ def test_round_trip_properties_at_benchmark_scale(capi):
     assert np.array_equal(x1[~m], x0[~m])
     assert not np.array_equal(x1[m], x0[m])
     s.close()
+
+
+@pytest.mark.parametrize("shape,relax,op", [((130, 77), "line-xy", "aniso9"), ((64, 301), "line-xy", "aniso9"),
+                                            ((200, 800), "line-y", "stretch5"), ((700, 90), "line-y", "aniso9")], ids=str)
+def test_y_lines_on_transposed_arrays_match_the_gather_pipeline(capi, monkeypatch, shape, relax, op):
+    """the resident solver runs y-line sweeps through the x-line kernel on transposed arrays (lines.hip
+    relax_lines_yt); same right-hand-side term order and the same scan as relax_lines_y, so the iterates are
+    bit-identical to the gather / solve / scatter pipeline (CEDAR_AMD_YLINES_TRANSPOSED=0), which the kernel
+    tests pin against the reference"""
+    nx, ny = shape
+    so = pb.aniso9(nx, ny) if op == "aniso9" else pb.diag_diffusion2(nx, ny, 1e-2, 1.0)
+    b = pb.rhs2(nx, ny)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CEDAR_AMD_YLINES_TRANSPOSED", flag)
+        s = capi.Solver(so, relax=relax, nrelax_pre=2, nrelax_post=1)
+        x = np.zeros_like(b)
+        h = s.solve(b, x)
+        s.close()
+        out[flag] = (np.array(h), x)
+    assert np.array_equal(out["0"][1], out["1"][1]), np.max(np.abs(out["0"][1] - out["1"][1]))
+    assert np.array_equal(out["0"][0], out["1"][0])
