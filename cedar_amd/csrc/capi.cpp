@@ -5,6 +5,7 @@
 #include "common.h"
 #include "stage.h"
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 
@@ -120,11 +121,12 @@ int cedar_amd_device_count(void)
 	return n;
 }
 int cedar_amd_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : 1; }
+void cedar_amd_memset(void *dst, int value, size_t bytes);
 void *cedar_amd_malloc(size_t bytes)
 {
 	void *p = nullptr;
 	CEDAR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
-	CEDAR_HIP_CHECK(hipMemsetAsync(p, 0, bytes, current_stream()));
+	cedar_amd_memset(p, 0, bytes);
 	return p;
 }
 void cedar_amd_free(void *p)
@@ -147,7 +149,11 @@ void cedar_amd_memcpy_d2d(void *dst, const void *src, size_t bytes)
 }
 void cedar_amd_memset(void *dst, int value, size_t bytes)
 {
-	CEDAR_HIP_CHECK(hipMemsetAsync(dst, value, bytes, current_stream()));
+	// zeroing whole doubles (every use the library itself makes) goes through its own kernel, see common.h zero_fill
+	if (value == 0 && bytes % sizeof(real_t) == 0 && (uintptr_t)dst % sizeof(real_t) == 0)
+		zero_fill(static_cast<real_t *>(dst), bytes / sizeof(real_t), current_stream());
+	else
+		CEDAR_HIP_CHECK(hipMemsetAsync(dst, value, bytes, current_stream()));
 }
 void cedar_amd_sync(void) { CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream())); }
 void cedar_amd_set_stream(void *s) { cedar_amd::g_stream = static_cast<hipStream_t>(s); }
@@ -192,8 +198,8 @@ void cedar_amd_gallery(int which, real_t *so, real_t *b, len_t nx, len_t ny, len
 	size_t npts = (size_t)(nx + 2) * (ny + 2) * (d3 ? nz + 2 : 1);
 	Staged sso(so, npts * nst_of[which], false, true);
 	Staged sb(b, npts, false, true);
-	CEDAR_HIP_CHECK(hipMemsetAsync(sso.get(), 0, npts * nst_of[which] * sizeof(real_t), current_stream()));
-	if (b) CEDAR_HIP_CHECK(hipMemsetAsync(sb.get(), 0, npts * sizeof(real_t), current_stream()));
+	zero_fill(sso.get(), npts * nst_of[which], current_stream());
+	if (b) zero_fill(sb.get(), npts, current_stream());
 	gallery_fill(which_in, sso.get(), sb.get(), (int)nx, (int)ny, d3 ? (int)nz : 1, params, current_stream());
 }
 

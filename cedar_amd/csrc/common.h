@@ -122,6 +122,10 @@ bool galerkin3_twostage(const real_t *so, real_t *soc, const real_t *ci, int IIF
                         int IIC, int JJC, int KKC, int ifd, hipStream_t st);
 void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                int IIC, int JJC, int KKC, int ifd, hipStream_t st);
+// util.hip: zero fill by a kernel of the library.  hipMemsetAsync is not used on solver data: under the HIP runtime
+// that PyTorch loads first (the multi-GPU path always imports torch) it left non-zero bit patterns in the cleared
+// arrays (profiles/r01_memset_under_torch_runtime.log)
+void zero_fill(real_t *p, size_t n, hipStream_t st);
 // lines.hip
 void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
 void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);

@@ -250,7 +250,7 @@ void affine_lines(real_t *y, const real_t *a, const real_t *div, int nlines, int
 }
 
 // doubles of LDS a line of n unknowns needs (padded line + scan scratch)
-static inline size_t line_lds_doubles(int n) { return (size_t)n + (size_t)(n >> 3) + 24; }
+static inline size_t line_lds_doubles(int n) { return (size_t)n + (size_t)(n >> 3) + 40; } // line + 16 + 16 wave aggregates + carry
 
 // ------------------------------------------------------------------ x-lines
 // Sherman-Morrison closure of a cyclic line held in LDS: y holds the solution of the folded system;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int npad = (II - 2) + ((II - 2) >> 3) + 1;
-	real_t *y = lds, *wa = lds + npad, *wc = wa + 4, *cs = wc + 4;
+	real_t *y = lds, *wa = lds + npad, *wc = wa + 16, *cs = wc + 16;
 	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nlines);
 	if (L >= (unsigned)nlines) return;
 	const size_t sj = II, PS = (size_t)II * JJ;
@@ -324,6 +324,15 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 	}
 }
 
+// lanes per line: one wavefront up to 512 unknowns, else CEDAR_AMD_LINE_BS (256 / 512 / 1024).  The size fixes the
+// association of the scan, so every launcher of a line solve takes it from here.
+static int line_bs(int n)
+{
+	if (n <= 512) return 64;
+	static const int e = getenv("CEDAR_AMD_LINE_BS") ? atoi(getenv("CEDAR_AMD_LINE_BS")) : 256;
+	return (e == 512 || e == 1024) ? e : 256;
+}
+
 // a line must fit the 160 KB of LDS (up to ~18,000 unknowns); longer lines are refused through the
 // host's print_error callback like every other unsupported request, the sweep is skipped
 extern "C" void print_error(char *msg);
@@ -349,17 +358,31 @@ static void launch_x_k(const real_t *so, const real_t *qf, real_t *q, const real
 }
 
 template <int BS>
-static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                     int nstncl, int jb, hipStream_t st, bool sm = false)
+static void launch_x_n(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
+                       int nstncl, int jb, hipStream_t st, bool sm, bool yt)
 {
 	int nlines = (JJ - 2 - jb + 1) / 2;
 	if (nlines <= 0) return;
-	if (nstncl == 5) {
+	if (yt) { // Dirichlet only
+		if (nstncl == 5) launch_x_k<BS, true, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
+		else launch_x_k<BS, false, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
+	} else if (nstncl == 5) {
 		if (sm) launch_x_k<BS, true, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
 		else launch_x_k<BS, true, false>(so, qf, q, sor, II, JJ, jb, nlines, st);
 	} else {
 		if (sm) launch_x_k<BS, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
 		else launch_x_k<BS, false, false>(so, qf, q, sor, II, JJ, jb, nlines, st);
+	}
+}
+
+static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
+                     int nstncl, int jb, hipStream_t st, bool sm = false, bool yt = false)
+{
+	switch (line_bs(II - 2)) {
+	case 64: launch_x_n<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt); break;
+	case 512: launch_x_n<512>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt); break;
+	case 1024: launch_x_n<1024>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt); break;
+	default: launch_x_n<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt);
 	}
 }
 
@@ -374,8 +397,7 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	for (int c = 0; c < 2; c++) {
 		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
 		int jb = (updown == BMG_DOWN) ? 1 - c : c;
-		if (II - 2 <= 512) launch_x<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm);
-		else launch_x<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm);
+		launch_x(so, qf, q, sor, II, JJ, nstncl, jb, st, sm);
 		if (sm) wrap2(q, II, JJ, 1, ipn == 3, 1, st);
 	}
 	if (ipn == 1) wrap2(q, II, JJ, 1, 1, 0, st);
@@ -425,7 +447,7 @@ __global__ __launch_bounds__(BS) void ylines_solve(real_t *__restrict__ bt, cons
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int n = JJ - 2;
 	const int npad = n + (n >> 3) + 1;
-	real_t *y = lds, *wa = lds + npad, *wc = wa + 4, *cs = wc + 4;
+	real_t *y = lds, *wa = lds + npad, *wc = wa + 16, *cs = wc + 16;
 	const unsigned L = blockIdx.x;
 	if (L >= (unsigned)nlines) return;
 	const size_t PS = (size_t)II * JJ;
@@ -462,6 +484,32 @@ __global__ __launch_bounds__(256) void ylines_scatter_T(const real_t *__restrict
 	}
 }
 
+template <int BS>
+static void launch_ysolve_n(real_t *bt, const real_t *sor, int II, int JJ, int ib, int nlines, int ldt, const real_t *so,
+                            int lofs, size_t shm, bool sm, hipStream_t st)
+{
+	if (sm) {
+		auto k = ylines_solve<BS, true>;
+		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+		hipLaunchKernelGGL(k, dim3(nlines), dim3(BS), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
+	} else {
+		auto k = ylines_solve<BS, false>;
+		if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+		hipLaunchKernelGGL(k, dim3(nlines), dim3(BS), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
+	}
+}
+
+static void launch_ysolve(real_t *bt, const real_t *sor, int II, int JJ, int ib, int nlines, int ldt, const real_t *so,
+                          int lofs, size_t shm, bool sm, hipStream_t st)
+{
+	switch (line_bs(JJ - 2)) {
+	case 64: launch_ysolve_n<64>(bt, sor, II, JJ, ib, nlines, ldt, so, lofs, shm, sm, st); break;
+	case 512: launch_ysolve_n<512>(bt, sor, II, JJ, ib, nlines, ldt, so, lofs, shm, sm, st); break;
+	case 1024: launch_ysolve_n<1024>(bt, sor, II, JJ, ib, nlines, ldt, so, lofs, shm, sm, st); break;
+	default: launch_ysolve_n<256>(bt, sor, II, JJ, ib, nlines, ldt, so, lofs, shm, sm, st);
+	}
+}
+
 size_t ylines_scratch_doubles(int II, int JJ)
 {
 	const int n = JJ - 2;
@@ -495,18 +543,7 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 				hipLaunchKernelGGL(ylines_rhs_T<true>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt, lofs);
 			else
 				hipLaunchKernelGGL(ylines_rhs_T<false>, tg, dim3(256), 0, st, so, qf, q, bt, II, JJ, ib, nlines, ldt, lofs);
-			if (n <= 512) {
-				if (sm) hipLaunchKernelGGL((ylines_solve<64, true>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
-				else hipLaunchKernelGGL((ylines_solve<64, false>), dim3(nlines), dim3(64), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
-			} else if (sm) {
-				auto k = ylines_solve<256, true>;
-				if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-				hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
-			} else {
-				auto k = ylines_solve<256, false>;
-				if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-				hipLaunchKernelGGL(k, dim3(nlines), dim3(256), shm, st, bt, sor, II, JJ, ib, nlines, ldt, so, lofs);
-			}
+			launch_ysolve(bt, sor, II, JJ, ib, nlines, ldt, so, lofs, shm, sm, st);
 			hipLaunchKernelGGL(ylines_scatter_T, tg, dim3(256), 0, st, bt, q, II, JJ, ib, nlines, ldt, lofs);
 		}
 		if (sm) wrap2(q, II, JJ, 1, 1, ipn == 3, st);
@@ -565,13 +602,7 @@ void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt,
 		const int nlines = (II - 2 - ib + 1) / 2;
 		if (nlines <= 0) continue;
 		// transposed grid: JJ is the fast extent, II the number of rows
-		if (JJ - 2 <= 512) {
-			if (nstncl == 5) launch_x_k<64, true, false, true>(sot, qft, qt, sor, JJ, II, ib, nlines, st);
-			else launch_x_k<64, false, false, true>(sot, qft, qt, sor, JJ, II, ib, nlines, st);
-		} else {
-			if (nstncl == 5) launch_x_k<256, true, false, true>(sot, qft, qt, sor, JJ, II, ib, nlines, st);
-			else launch_x_k<256, false, false, true>(sot, qft, qt, sor, JJ, II, ib, nlines, st);
-		}
+		launch_x(sot, qft, qt, sor, JJ, II, nstncl, ib, st, false, true);
 	}
 	transpose2(qt, q, JJ, II, st);
 }

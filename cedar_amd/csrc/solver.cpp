@@ -43,7 +43,7 @@ real_t *dalloc(size_t n)
 	void *p = nullptr;
 	size_t bytes = (n ? n : 1) * sizeof(real_t);
 	CEDAR_HIP_CHECK(hipMalloc(&p, bytes));
-	CEDAR_HIP_CHECK(hipMemsetAsync(p, 0, bytes, current_stream()));
+	zero_fill(static_cast<real_t *>(p), bytes / sizeof(real_t), current_stream());
 	return static_cast<real_t *>(p);
 }
 
@@ -174,7 +174,7 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
 	else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
 	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
-	CEDAR_HIP_CHECK(hipMemsetAsync(K.x, 0, K.npts * sizeof(real_t), st)); // coarse_x.set(0.0)
+	zero_fill(K.x, K.npts, st); // coarse_x.set(0.0)
 	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
 	else ncycle(s, lvl + 1, K.x, K.b, st);
 	if (s->nd == 2 && s->st.ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, s->st.ibc, st);
@@ -196,8 +196,8 @@ void fmg_cycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStre
 	if (s->nd == 2) restrict2(b, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
 	else restrict3(b, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
 	fmg_cycle(s, lvl + 1, K.x, K.b, st);
-	CEDAR_HIP_CHECK(hipMemsetAsync(x, 0, L.npts * sizeof(real_t), st));
-	CEDAR_HIP_CHECK(hipMemsetAsync(L.res, 0, L.npts * sizeof(real_t), st));
+	zero_fill(x, L.npts, st);
+	zero_fill(L.res, L.npts, st);
 	if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
 	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
 	ncycle(s, lvl, x, b, st);
@@ -404,6 +404,9 @@ size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what
 	else if (!strcmp(what, "SOR0")) { src = L.SOR0; n = L.npts * 2; }
 	else if (!strcmp(what, "SOR1")) { src = L.SOR1; n = L.SOR1 ? L.npts * 2 : 0; }
 	else if (!strcmp(what, "ABD")) { src = s->ABD; n = (size_t)s->nabd1 * s->nabd2; }
+	else if (!strcmp(what, "res")) { src = L.res; n = L.npts; }
+	else if (!strcmp(what, "x")) { src = L.x; n = L.x ? L.npts : 0; } // coarse levels only: level 0 uses the caller's
+	else if (!strcmp(what, "b")) { src = L.b; n = L.b ? L.npts : 0; }
 	if (out && n) cedar_amd_memcpy_d2h(out, src, n * sizeof(real_t));
 	return n;
 }
