@@ -229,7 +229,8 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 void cedar_amd_solver_destroy(cedar_amd_solver *s);
 int cedar_amd_solver_nlevels(const cedar_amd_solver *s);
 void cedar_amd_solver_level_dims(const cedar_amd_solver *s, int lvl, len_t *nx, len_t *ny, len_t *nz);
-/* copy a level array to the host for inspection: what = "A","P","SOR0","SOR1","ABD";
+/* copy a level array to the host for inspection: what = "A","P","SOR0","SOR1","ABD","res", and on coarse
+ * levels "x","b" (level 0 works on the caller's x and b);
  * returns the number of doubles written (0 if absent); out may be NULL to query. */
 size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what, real_t *out);
 /* one V-cycle, cycle->run(x,b): x,b host or device */
