@@ -1,4 +1,4 @@
-"""ad-hoc first GPU run: parity of relax/residual vs the oracle + relax sweep timing"""
+"""(kept under tests/ because it calls the oracle as the checker) ad-hoc first GPU run: parity of relax/residual vs the oracle + relax sweep timing"""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -223,3 +223,32 @@ def test_two_stage_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeyp
         out.append(soc)
     assert np.any(out[0] != 0)
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
+def _random_cases(nd, count, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    out = []
+    for c in range(count):
+        dims = [int(v) for v in rng.integers(lo, hi + 1, size=nd)]
+        if nd == 2:
+            nst = int(rng.choice([3, 5]))
+            out.append(("rnd_%s_%d" % ("x".join(map(str, dims)), nst), dims[0], dims[1], nst))
+        else:
+            nst = int(rng.choice([4, 14]))
+            out.append(("rnd_%s_%d" % ("x".join(map(str, dims)), nst), dims[0], dims[1], dims[2], nst))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(2, 16, 20261004, 3, 150), ids=lambda c: c[0])
+def test_kernels_2d_random_shapes_vs_oracle(K, oracle, case):
+    """seeded random extents (odd, even, down to 3) and both stencils through every 2D kernel of the suite"""
+    got, want = cases.kernel_suite_2d(K, case), cases.kernel_suite_2d(oracle, case)
+    for k in want:
+        check(f"{case[0]}/{k}", got[k], want[k])
+
+
+@pytest.mark.parametrize("case", _random_cases(3, 16, 20261005, 3, 36), ids=lambda c: c[0])
+def test_kernels_3d_random_shapes_vs_oracle(K, oracle, case):
+    got, want = cases.kernel_suite_3d(K, case), cases.kernel_suite_3d(oracle, case)
+    for k in want:
+        check(f"{case[0]}/{k}", got[k], want[k])

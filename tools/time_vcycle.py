@@ -1,7 +1,7 @@
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from cedar_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 so, b = capi.gallery("fe3", (n, n, n))
