@@ -533,9 +533,11 @@ static int plane_frun(int JJ)
 // ghost row (2 <= j <= ny-1, 2 <= k <= nz-1 in 1-based interior numbering 1..n); 2 = the others (the
 // shell).  Rows of one class do not couple, so part 1 then part 2 equals part 0; the interior rows do
 // not read the y/z ghost layers and can run while those are still being exchanged.
+// sides: which faces of the box have a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z); rows next to a face
+// without one read no exchanged ghost and count as interior.
 template <int BS>
 static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                        int II, int JJ, int KK, int jb, int kb, int part, hipStream_t st)
+                        int II, int JJ, int KK, int jb, int kb, int part, int sides, hipStream_t st)
 {
 	const int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
 	if (nrj <= 0 || nrk <= 0) return;
@@ -544,9 +546,9 @@ static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t 
 		return;
 	}
 	// class rows j = 1+jb+2 jr (0-based incl. ghost): j = 1 is in the class iff jb = 0, j = ny iff it has the class parity
-	const int jlo = jb == 0 ? 1 : 0, klo = kb == 0 ? 1 : 0;
-	const int jhi = (1 + jb + 2 * (nrj - 1) == JJ - 2) ? nrj - 1 : nrj;
-	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2) ? nrk - 1 : nrk;
+	const int jlo = (jb == 0 && (sides & 1)) ? 1 : 0, klo = (kb == 0 && (sides & 4)) ? 1 : 0;
+	const int jhi = (1 + jb + 2 * (nrj - 1) == JJ - 2 && (sides & 2)) ? nrj - 1 : nrj;
+	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2 && (sides & 8)) ? nrk - 1 : nrk;
 	const int nji = jhi - jlo > 0 ? jhi - jlo : 0, nki = khi - klo > 0 ? khi - klo : 0;
 	if (part == 1) {
 		launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jlo, 2, nji, kb, nki, st, klo);
@@ -557,20 +559,22 @@ static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t 
 		return;
 	}
 	// shell = planes below klo / from khi (all rows), and in the planes between: rows below jlo / from jhi
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, klo, st, 0);
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, nrk - khi, st, khi);
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, jlo, kb, nki, st, klo);
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jhi, 2, nrj - jhi, kb, nki, st, klo);
+	if (klo > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, klo, st, 0);
+	if (nrk - khi > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, nrk - khi, st, khi);
+	if (jlo > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, jlo, kb, nki, st, klo);
+	if (nrj - jhi > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jhi, 2, nrj - jhi, kb, nki, st, klo);
 }
 
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part)
+                   int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part_sides)
 {
+	// part_sides = part | sides << 4 (include/cedar_amd.h); no side bit set = every face has a neighbour
+	const int part = part_sides & 3, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	const int npairs = (II - 2 + 1) / 2;
-	if (npairs <= 64) launch_part<64>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
-	else if (npairs <= 128) launch_part<128>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
-	else if (npairs <= 256) launch_part<256>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
-	else if (npairs <= 512) launch_part<512>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, st);
+	if (npairs <= 64) launch_part<64>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
+	else if (npairs <= 128) launch_part<128>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
+	else if (npairs <= 256) launch_part<256>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
+	else if (npairs <= 512) launch_part<512>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
 	else {
 		if (part == 1) return; // rows too long for the row kernel: everything goes with the shell
 		for (int c = 0; c < 2; c++) {
@@ -634,13 +638,14 @@ static void planes_bs(bool up, const real_t *so, const real_t *qf, real_t *q, co
 }
 
 void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                     int II, int JJ, int KK, int kb, int up, int part, hipStream_t st)
+                     int II, int JJ, int KK, int kb, int up, int part_sides, hipStream_t st)
 {
+	const int part = part_sides & 3, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	const int nrk = (KK - 2 - kb + 1) / 2;
 	if (II < 3 || JJ < 3 || nrk <= 0) return;
 	const int npairs = (II - 2 + 1) / 2;
-	const int klo = kb == 0 ? 1 : 0;
-	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2) ? nrk - 1 : nrk;
+	const int klo = (kb == 0 && (sides & 4)) ? 1 : 0;
+	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2 && (sides & 8)) ? nrk - 1 : nrk;
 	const int nki = khi - klo > 0 ? khi - klo : 0;
 	// (kr0, count) pieces of the requested part
 	int pieces[2][2] = { { 0, nrk }, { 0, 0 } };

@@ -262,12 +262,14 @@ class GpuBackend:
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
-    def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0):
+    def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0, sides=0):
+        """sides: faces of the box with a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z; 0 = all), see cedar_amd.h"""
         self.lib.cedar_amd_relax3_pass_part(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x),
-                                            jb, kb, int(efirst), part)
+                                            jb, kb, int(efirst), part | (sides << 4))
 
-    def relax_planes(self, A, b, x, sor, kb, up, part=0):
-        self.lib.cedar_amd_relax3_planes(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), kb, int(up), part)
+    def relax_planes(self, A, b, x, sor, kb, up, part=0, sides=0):
+        self.lib.cedar_amd_relax3_planes(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), kb, int(up),
+                                         part | (sides << 4))
 
     class _Side:
         """`with backend.side() as h:` issues the enclosed work (library launches and collectives) on a
@@ -465,6 +467,8 @@ class DistSolver3:
         self.pre, self.post, self.max_iter, self.tol = nrelax_pre, nrelax_post, max_iter, tol
         self.min_coarse = min_coarse
         self.overlap_min = overlap_min
+        # faces of the box with a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z): only rows next to those wait for a halo
+        self.sides = (int(topo.has(1, -1)) | int(topo.has(1, +1)) << 1 | int(topo.has(2, -1)) << 2 | int(topo.has(2, +1)) << 3)
         staged = dist.is_initialized() and dist.get_backend() == "gloo" and A_local.is_cuda
         nst = A_local.shape[0]
         n = tuple(int(s) - 2 for s in A_local.shape[1:][::-1])
@@ -572,11 +576,11 @@ class DistSolver3:
                 for c in range(2):
                     kb = c if up else 1 - c
                     if L.overlap:
-                        be.relax_planes(L.A, b, x, L.sor, kb, up, 1)
+                        be.relax_planes(L.A, b, x, L.sor, kb, up, 1, self.sides)
                         if pending is not None:
                             be.wait(pending)
                             pending = None
-                        be.relax_planes(L.A, b, x, L.sor, kb, up, 2)
+                        be.relax_planes(L.A, b, x, L.sor, kb, up, 2, self.sides)
                         with be.side() as pending:
                             L.halo.exchange(x)
                     else:
@@ -589,11 +593,11 @@ class DistSolver3:
                 if L.overlap:
                     # interior rows first: they read no y/z ghost, whose exchange (previous pass) may
                     # still be running on the side stream; then join and do the shell rows
-                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up, 1)
+                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up, 1, self.sides)
                     if pending is not None:
                         be.wait(pending)
                         pending = None
-                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up, 2)
+                    be.relax_pass(L.A, b, x, L.sor, jb, kb, up, 2, self.sides)
                 else:
                     be.relax_pass(L.A, b, x, L.sor, jb, kb, up)
                 if t.p[0] > 1:

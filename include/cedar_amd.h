@@ -148,12 +148,15 @@ void cedar_amd_relax3_pass(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t
                            int jb, int kb, int efirst);
 /* the same restricted to a part of the class rows: part 1 = rows none of whose j,k neighbours is a
  * ghost row (they do not read the y/z ghost layers and may run while those are being exchanged),
- * part 2 = the remaining shell, part 0 = all.  Rows of a class do not couple: 1 then 2 equals 0. */
+ * part 2 = the remaining shell, part 0 = all.  Rows of a class do not couple: 1 then 2 equals 0.
+ * part may carry, shifted left by 4, the faces of the box that have a neighbouring rank (bit 0 -y, 1 +y, 2 -z,
+ * 3 +z): rows next to a face without one read no exchanged ghost and count as interior; no bit set = all four. */
 void cedar_amd_relax3_pass_part(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                                 int jb, int kb, int efirst, int part);
 /* both row classes of the planes of k-parity kb in sweep order (up != 0: the UP order): the unit between two
  * halo exchanges on a slab decomposition (rank grid 1 x 1 x pz), run with the plane-fused kernel on big
- * levels.  part: 0 = all planes of the parity, 1 = planes whose k-neighbours are both owned, 2 = the others. */
+ * levels.  part: 0 = all planes of the parity, 1 = planes whose k-neighbours are both owned, 2 = the others;
+ * the -z / +z bits of the face mask of cedar_amd_relax3_pass_part apply (part | sides << 4). */
 void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                              int kb, int up, int part);
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */

@@ -120,13 +120,16 @@ void orc3_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real
  * Rows of one colour do not couple, so interior-then-shell equals the plain colour pass; the
  * domain-decomposed driver computes the interior while the previous halo is still in flight. */
 void orc3_relax_colour_part(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                            len_t II, len_t JJ, len_t KK, int pts, int part)
+                            len_t II, len_t JJ, len_t KK, int pts, int part_sides)
 {
+	/* part_sides = part | sides << 4; sides: faces with a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z), none set = all */
+	const int part = part_sides & 7, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	int I1 = (int)II - 1, J1 = (int)JJ - 1, K1 = (int)KK - 1;
 	for (int k = 2 + ((pts - 1) / 4) % 2; k <= K1; k += 2)
 		for (int j = 2 + ((pts - 1) / 2) % 2; j <= J1; j += 2) {
-			const int inner = j >= 3 && j <= J1 - 1 && k >= 3 && k <= K1 - 1;
-			const int kinner = k >= 3 && k <= K1 - 1; /* parts 3 / 4: planes with both k-neighbours owned / the others */
+			/* parts 3 / 4: planes with both k-neighbours owned (or no rank beyond them) / the others */
+			const int kinner = (k >= 3 || !(sides & 4)) && (k <= K1 - 1 || !(sides & 8));
+			const int inner = (j >= 3 || !(sides & 1)) && (j <= J1 - 1 || !(sides & 2)) && kinner;
 			if ((part == 1 && !inner) || (part == 2 && inner) || (part == 3 && !kinner) || (part == 4 && kinner)) continue;
 			for (int i = 2 + (pts - 1) % 2; i <= I1; i += 2)
 				Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);

@@ -21,18 +21,18 @@ class CpuBackend:
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64)
 
-    def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0):
+    def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0, sides=0):
         # the fused device kernel = the two i-colours of the row class back to back, no exchange between;
         # part 1 / 2 = interior rows / shell rows of the class (cedar_amd_relax3_pass_part)
         for ib in ((0, 1) if efirst else (1, 0)):
-            self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, part)
+            self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, part | (sides << 4))
 
-    def relax_planes(self, A, b, x, sor, kb, up, part=0):
+    def relax_planes(self, A, b, x, sor, kb, up, part=0, sides=0):
         # cedar_amd_relax3_planes: both row classes of the planes of parity kb in sweep order
         opart = {0: 0, 1: 3, 2: 4}[part]
         for jb in ((0, 1) if up else (1, 0)):
             for ib in ((0, 1) if up else (1, 0)):
-                self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, opart)
+                self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, opart | (sides << 4))
 
     class _Side:  # CPU: no streams, the "side" work simply runs in program order
         def __enter__(self):

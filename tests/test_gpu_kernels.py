@@ -124,11 +124,15 @@ def test_partial_row_class_passes_compose_to_the_full_pass(shape):
     for jb in (0, 1):
         for kb in (0, 1):
             for efirst in (0, 1):
-                whole, parts = q0.copy(), q0.copy()
+                whole = q0.copy()
                 f(capi._p(so), capi._p(qf), capi._p(whole), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), jb, kb, efirst, 0)
-                for part in (1, 2):
-                    f(capi._p(so), capi._p(qf), capi._p(parts), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), jb, kb, efirst, part)
-                assert np.array_equal(whole, parts), (shape, jb, kb, efirst)
+                # with every face mask (which faces have a neighbouring rank: bit 0 -y, 1 +y, 2 -z, 3 +z; 0 = all)
+                for sides in (0, 1, 2, 4, 8, 5, 10, 15):
+                    parts = q0.copy()
+                    for part in (1, 2):
+                        f(capi._p(so), capi._p(qf), capi._p(parts), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), jb, kb, efirst,
+                          part | (sides << 4))
+                    assert np.array_equal(whole, parts), (shape, jb, kb, efirst, sides)
                 assert not np.array_equal(whole, q0) or ((ny - jb + 1) // 2 == 0 or (nz - kb + 1) // 2 == 0)
 
 
@@ -153,14 +157,19 @@ def test_plane_parity_passes_compose_to_the_sweep(K, oracle, monkeypatch, shape,
     for up in (0, 1):
         want = q0.copy()
         oracle.relax3(so, qf, want, sor, up)
-        whole, parts = q0.copy(), q0.copy()
+        whole = q0.copy()
         for c in range(2):
             kb = c if up else 1 - c
             f(capi._p(so), capi._p(qf), capi._p(whole), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), kb, up, 0)
-            for part in (1, 2):
-                f(capi._p(so), capi._p(qf), capi._p(parts), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), kb, up, part)
         assert np.array_equal(whole, want), (shape, frun, up)
-        assert np.array_equal(parts, want), (shape, frun, up)
+        for sides in (0, 4, 8, 12):  # which z faces have a neighbouring rank (0 = both)
+            parts = q0.copy()
+            for c in range(2):
+                kb = c if up else 1 - c
+                for part in (1, 2):
+                    f(capi._p(so), capi._p(qf), capi._p(parts), capi._p(sor), u(nx + 2), u(ny + 2), u(nz + 2), kb, up,
+                      part | (sides << 4))
+            assert np.array_equal(parts, want), (shape, frun, up, sides)
 
 
 def test_device_pointers_are_used_in_place(K):
