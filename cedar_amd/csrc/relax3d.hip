@@ -627,7 +627,10 @@ static void planes_bs(bool up, const real_t *so, const real_t *qf, real_t *q, co
 	if (nrk <= 0) return;
 	const int jbF = up ? 0 : 1;
 	const int frun = plane_frun(JJ);
-	if (frun > 0) {
+	// the fused kernel gives one workgroup a run of frun rows: a piece of one or two planes (the shell of a slab)
+	// would occupy a fraction of the CUs for eight row tasks in a row -- such pieces take the row kernels
+	const int nF = (JJ - 2 - jbF + 1) / 2;
+	if (frun > 0 && (size_t)nrk * (size_t)((nF + frun - 1) / frun) >= 256) {
 		launch_plane<BS>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st, kr0, nrk);
 		return;
 	}
