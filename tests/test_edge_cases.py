@@ -121,3 +121,32 @@ def test_gpu_early_exit_and_fcycle_direct():
     h = s.solve(b, x)
     s.close()
     assert len(h) < 11 and h[-1] < 1e-3 and h[-2] >= 1e-3
+
+
+@pytest.mark.parametrize("shape", [(8, 6, 6), (9, 7, 5), (12, 4, 3), (6, 3, 4)], ids=str)
+def test_oracle_row_class_parts_compose_for_every_face_mask(oracle, shape):
+    """the checker's side of cedar_amd_relax3_pass_part / _planes: interior + shell (parts 1+2, plane parts 3+4) equal the
+    whole colour for every set of faces that have a neighbouring rank, and a face without a neighbour moves its rows
+    from the shell to the interior"""
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    so = pb.random_op(g, 14, 71, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 72, -1, 1), pb.uniform(g, 73, -1, 1)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip3(so, sor)
+    for pts in range(1, 9):
+        whole = q0.copy()
+        oracle.relax_colour3_part(so, qf, whole, sor, pts, 0)
+        for sides in range(16):
+            for pa, pb_ in ((1, 2), (3, 4)):
+                parts = q0.copy()
+                oracle.relax_colour3_part(so, qf, parts, sor, pts, pa | (sides << 4))
+                first = parts.copy()
+                oracle.relax_colour3_part(so, qf, parts, sor, pts, pb_ | (sides << 4))
+                assert np.array_equal(parts, whole), (shape, pts, sides, pa)
+                if sides and pa == 1:
+                    # rows of the first / last owned row or plane are interior exactly when that face has no neighbour
+                    jj, kk = 1 + ((pts - 1) // 2) % 2, 1 + ((pts - 1) // 4) % 2
+                    if jj == 1 and kk + 2 <= nz and kk > 1 or (jj == 1 and not (sides & 4) and kk == 1 and nz > 1):
+                        touched = not np.array_equal(first[kk, 1, :], q0[kk, 1, :])
+                        assert touched == (not (sides & 1)) or nx < 1
