@@ -11,5 +11,4 @@ x = capi.DeviceArray(b.shape)
 for _ in range(2): s.vcycle(x, b)
 capi.sync()
 ms = s.time_vcycles(x, b, 5) / 5
-# correctness spot check of the experimental order against the default order is done in tests
 print("vcycle %.3f ms" % ms, "x_l2 %.15e" % capi.l2norm(x))
