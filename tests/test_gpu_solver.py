@@ -134,9 +134,10 @@ def test_round_trip_properties_at_benchmark_scale(capi):
     s.close()
 
 
-@pytest.mark.parametrize("shape,relax,op", [((130, 77), "line-xy", "aniso9"), ((64, 301), "line-xy", "aniso9"),
-                                            ((200, 800), "line-y", "stretch5"), ((700, 90), "line-y", "aniso9")], ids=str)
-def test_y_lines_on_transposed_arrays_match_the_gather_pipeline(capi, monkeypatch, shape, relax, op):
+@pytest.mark.parametrize("shape,relax,op,cycle", [((130, 77), "line-xy", "aniso9", "v"), ((64, 301), "line-xy", "aniso9", "v"),
+                                                  ((200, 800), "line-y", "stretch5", "v"), ((700, 90), "line-y", "aniso9", "v"),
+                                                  ((96, 130), "line-xy", "aniso9", "f"), ((257, 33), "line-y", "stretch5", "f")], ids=str)
+def test_y_lines_on_transposed_arrays_match_the_gather_pipeline(capi, monkeypatch, shape, relax, op, cycle):
     """the resident solver runs y-line sweeps through the x-line kernel on transposed arrays (lines.hip
     relax_lines_yt); same right-hand-side term order and the same scan as relax_lines_y, so the iterates are
     bit-identical to the gather / solve / scatter pipeline (CEDAR_AMD_YLINES_TRANSPOSED=0), which the kernel
@@ -147,7 +148,7 @@ def test_y_lines_on_transposed_arrays_match_the_gather_pipeline(capi, monkeypatc
     out = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("CEDAR_AMD_YLINES_TRANSPOSED", flag)
-        s = capi.Solver(so, relax=relax, nrelax_pre=2, nrelax_post=1)
+        s = capi.Solver(so, relax=relax, nrelax_pre=2, nrelax_post=1, cycle=cycle)
         x = np.zeros_like(b)
         h = s.solve(b, x)
         s.close()
