@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--workload", default="3d27", choices=list(WORKLOADS))
     ap.add_argument("--size", type=int, default=0, help="override the per-GPU grid extent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="3D, N>1: keep the GLOBAL grid at --size^3 and split it over the ranks (strong scaling); "
+                         "default is --size^3 per GPU (weak scaling, what the driver's scaling table uses)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,13 +200,19 @@ def main():
         dev = torch.device("cuda", local_rank)
         if nd == 3:
             topo = Topology(rank, world)
-            g = (n + 2, n + 2, n + 2)
+            ln = [n, n, n]  # local extents
+            if args.strong:
+                if any(n % topo.p[d] or (n // topo.p[d]) % 16 for d in range(3)):
+                    raise SystemExit("bench.py --strong: %d does not split into even local extents over %s" % (n, topo.p))
+                ln = [n // topo.p[d] for d in range(3)]
+            g = (ln[2] + 2, ln[1] + 2, ln[0] + 2)
             A = torch.zeros((14,) + g, dtype=torch.float64, device=dev)
             bt = torch.zeros(g, dtype=torch.float64, device=dev)
             import ctypes as C
-            place = [float(topo.coord[d] * n) for d in range(3)] + [float(n * topo.p[d]) for d in range(3)]
+            place = [float(topo.coord[d] * ln[d]) for d in range(3)] + [float(ln[d] * topo.p[d]) for d in range(3)]
             pp = (C.c_double * 6)(*place)
-            capi.lib.cedar_amd_gallery(112, A.data_ptr(), bt.data_ptr(), n, n, n, pp)  # fe3 placed in the global grid
+            capi.lib.cedar_amd_gallery(112, A.data_ptr(), bt.data_ptr(), ln[0], ln[1], ln[2], pp)  # fe3 placed in the global grid
+            dof = float(ln[0]) * ln[1] * ln[2]
             dsolver = DistSolver3(GpuBackend(dev), topo, A)
         else:
             # 2D workloads: n^2 per GPU of a (px n) x (py n) global grid, cedar_amd/dist2d.py.  The
@@ -303,16 +312,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.strong and world > 1 and nd == 3) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": label.format(n=n) + (", %d GPUs" % world if world > 1 else ""),
-                       "grid_per_gpu": [n] * nd, "levels": solver.nlevels(), "cycle": "V(2,1)",
+                       "grid_per_gpu": ([int(v) for v in ln] if (world > 1 and nd == 3) else [n] * nd), "levels": solver.nlevels(), "cycle": "V(2,1)",
                        "relaxation": relax,
                        "parallelism": "single GPU" if world == 1 else
-                       "domain decomposition %s ranks, %d^%d per GPU, halo exchange over %s" %
-                       ("x".join(map(str, topo.p[:nd])), n, nd, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
+                       "domain decomposition %s ranks, %s per GPU, halo exchange over %s" %
+                       ("x".join(map(str, topo.p[:nd])),
+                        "x".join(str(int(v)) for v in ln) if nd == 3 else "%d^2" % n,
+                        "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
             "roofline": roofline,
             "setup_ms": None if t_setup is None else t_setup * 1e3,  # device-side interp + Galerkin + relax set-up
         }
