@@ -327,6 +327,30 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 	relax27_row_task<BS, EFIRST, NT>(so, qf, q, sor, II, sj, sk, PS, j * sj + k * sk, xch);
 }
 
+// The shell of a row class (rows next to a face shared with another rank) is up to four thin rectangles of
+// (row, plane) pairs: one launch over their union instead of one latency-bound launch each.
+struct ShellRects {
+	int n;
+	int j0[4], nrj[4], kr0[4], start[5]; // rows j0 + 2 jr (jr < nrj) of the planes kr0 + kr; start = first workgroup of a rectangle
+};
+
+template <int BS, bool EFIRST, bool NT>
+__global__ __launch_bounds__(BS) void relax27_rows_shell(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                          real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                          int II, int JJ, int KK, int kb, ShellRects rc)
+{
+	__shared__ real_t xch[BS + 2];
+	const int b = (int)blockIdx.x;
+	int r = 0;
+#pragma unroll
+	for (int t = 1; t < 4; t++)
+		if (t < rc.n && b >= rc.start[t]) r = t;
+	const int w = b - rc.start[r];
+	const size_t j = (size_t)(rc.j0[r] + 2 * (w % rc.nrj[r])), k = (size_t)(1 + kb + 2 * (rc.kr0[r] + w / rc.nrj[r]));
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
+	relax27_row_task<BS, EFIRST, NT>(so, qf, q, sor, II, sj, sk, PS, j * sj + k * sk, xch);
+}
+
 // Plane-fused pass: both row classes of the planes of one k-parity in ONE launch.  In a plane the
 // sweep relaxes the rows of class F (j-parity jbF) before those of class S; an S row reads the fresh
 // values of its two F neighbours j-1, j+1 and nothing else of this plane class changes under it.  A
@@ -559,10 +583,30 @@ static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t 
 		return;
 	}
 	// shell = planes below klo / from khi (all rows), and in the planes between: rows below jlo / from jhi
-	if (klo > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, klo, st, 0);
-	if (nrk - khi > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, nrj, kb, nrk - khi, st, khi);
-	if (jlo > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, jlo, kb, nki, st, klo);
-	if (nrj - jhi > 0) launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jhi, 2, nrj - jhi, kb, nki, st, klo);
+	ShellRects rc;
+	rc.n = 0;
+	rc.start[0] = 0;
+	auto add = [&](int j0, int nj, int kr0, int nk) {
+		if (nj <= 0 || nk <= 0) return;
+		rc.j0[rc.n] = j0; rc.nrj[rc.n] = nj; rc.kr0[rc.n] = kr0;
+		rc.start[rc.n + 1] = rc.start[rc.n] + nj * nk;
+		rc.n++;
+	};
+	add(1 + jb, nrj, 0, klo);
+	add(1 + jb, nrj, khi, nrk - khi);
+	add(1 + jb, jlo, klo, nki);
+	add(1 + jb + 2 * jhi, nrj - jhi, klo, nki);
+	if (rc.n == 0) return;
+	for (int t = rc.n; t < 4; t++) { rc.j0[t] = 0; rc.nrj[t] = 1; rc.kr0[t] = 0; rc.start[t + 1] = rc.start[rc.n]; }
+	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
+	const dim3 grid((unsigned)rc.start[rc.n]);
+	if (efirst) {
+		if (nt) hipLaunchKernelGGL((relax27_rows_shell<BS, true, true>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
+		else hipLaunchKernelGGL((relax27_rows_shell<BS, true, false>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
+	} else {
+		if (nt) hipLaunchKernelGGL((relax27_rows_shell<BS, false, true>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
+		else hipLaunchKernelGGL((relax27_rows_shell<BS, false, false>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
+	}
 }
 
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
