@@ -210,6 +210,9 @@ void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF
 	if (!generic) {
 		// CEDAR_AMD_GALERKIN_TWOSTAGE=1 selects the experimental two-stage product (galerkin3_twostage.hip: same
 		// coarse operators bit for bit, measured slower than the one-stage kernels -- profiles/r01_experiment_galerkin_twostage.log)
+		// CEDAR_AMD_GALERKIN_TILED=1: fine operator staged through LDS, all fourteen slots per tile (galerkin3_tiled.hip)
+		const char *e3 = getenv("CEDAR_AMD_GALERKIN_TILED");
+		if (e3 && atoi(e3) == 1 && galerkin3_tiled(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
 		const char *e2 = getenv("CEDAR_AMD_GALERKIN_TWOSTAGE");
 		if (e2 && atoi(e2) == 1 && galerkin3_twostage(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
 		galerkin3_part0(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);

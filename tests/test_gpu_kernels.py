@@ -261,3 +261,21 @@ def test_kernels_3d_random_shapes_vs_oracle(K, oracle, case):
     got, want = cases.kernel_suite_3d(K, case), cases.kernel_suite_3d(oracle, case)
     for k in want:
         check(f"{case[0]}/{k}", got[k], want[k])
+
+
+@pytest.mark.parametrize("shape", [(9, 8, 7), (12, 12, 12), (33, 20, 17), (20, 33, 40)], ids=str)
+def test_lds_tiled_galerkin_is_bit_identical_to_the_slot_kernels(K, monkeypatch, shape):
+    """the opt-in LDS-tiled product (galerkin3_tiled.hip) evaluates the same rap_slot<S> from a staged tile"""
+    import problems as pb
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    gc = pb.coarse_shape(g)
+    so = pb.random_op(g, 14, 5, zero_ghost=False)
+    ci = pb.uniform((26,) + gc, 6, -1, 1)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_TILED", flag)
+        soc = np.zeros((14,) + gc)
+        K.galerkin3(so, soc, ci)
+        out.append(soc)
+    assert np.any(out[0] != 0) and np.array_equal(out[0], out[1])
