@@ -118,6 +118,10 @@ void setup_interp3_phase(const real_t *so, real_t *ci, int IIF, int JJF, int KKF
 // galerkin.hip
 void galerkin2(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int IIC, int JJC,
                int ifd, hipStream_t st);
+void galerkin3_fused27(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
+                       int IIC, int JJC, int KKC, hipStream_t st);
+void galerkin3_fused7(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
+                      int IIC, int JJC, int KKC, hipStream_t st);
 bool galerkin3_tiled(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                      int IIC, int JJC, int KKC, int ifd, hipStream_t st);
 bool galerkin3_twostage(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,

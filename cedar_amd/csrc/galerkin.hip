@@ -195,30 +195,24 @@ __global__ __launch_bounds__(256) void galerkin3_kernel(const real_t *__restrict
 	    = (s == KP) ? acc : -acc;
 }
 
-#define G3PART(n) void galerkin3_part##n(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF, \
-                                        int IIC, int JJC, int KKC, int ifd, hipStream_t st);
-G3PART(0) G3PART(1) G3PART(2) G3PART(3)
-#undef G3PART
-
 void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                int IIC, int JJC, int KKC, int ifd, hipStream_t st)
 {
 	if (IIC < 3 || JJC < 3 || KKC < 3) return;
-	// default: compile-time specialised kernels (galerkin3_unrolled.inc); the table-driven kernel below
-	// is the readable statement of the same sum and stays selectable for cross-checks
+	// default: compile-time specialised product, the fourteen slots of a coarse row in one XCD-contiguous launch
+	// (galerkin3_unrolled.inc, galerkin3_fused.inc); the table-driven kernel below is the readable statement of the
+	// same sum and stays selectable for cross-checks
 	static const bool generic = getenv("CEDAR_AMD_GALERKIN_GENERIC") && atoi(getenv("CEDAR_AMD_GALERKIN_GENERIC")) != 0;
 	if (!generic) {
-		// CEDAR_AMD_GALERKIN_TWOSTAGE=1 selects the experimental two-stage product (galerkin3_twostage.hip: same
-		// coarse operators bit for bit, measured slower than the one-stage kernels -- profiles/r01_experiment_galerkin_twostage.log)
-		// CEDAR_AMD_GALERKIN_TILED=1: fine operator staged through LDS, all fourteen slots per tile (galerkin3_tiled.hip)
+		// measured-slower experimental variants, same coarse operators bit for bit:
+		// CEDAR_AMD_GALERKIN_TILED=1 fine operator staged through LDS (profiles/r01_experiment_galerkin_lds_tiled.log),
+		// CEDAR_AMD_GALERKIN_TWOSTAGE=1 T = A P per fine point, then P^T T (profiles/r01_experiment_galerkin_twostage.log)
 		const char *e3 = getenv("CEDAR_AMD_GALERKIN_TILED");
 		if (e3 && atoi(e3) == 1 && galerkin3_tiled(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
 		const char *e2 = getenv("CEDAR_AMD_GALERKIN_TWOSTAGE");
 		if (e2 && atoi(e2) == 1 && galerkin3_twostage(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
-		galerkin3_part0(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
-		galerkin3_part1(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
-		galerkin3_part2(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
-		galerkin3_part3(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st);
+		if (ifd == 1) galerkin3_fused7(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, st);
+		else galerkin3_fused27(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, st);
 		return;
 	}
 	static bool ready = false;
