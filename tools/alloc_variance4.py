@@ -32,9 +32,13 @@ def sweep(v):
 probe.vmm_free.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
 import statistics
 res = {}
-for rnd in range(5):
-    for how, chunk, align in (("hipMalloc", -1, 0), ("vmm one handle", 0, 0), ("vmm 4 GB chunks", 4 << 30, 0), ("vmm 1 GB chunks", 1 << 30, 0),
-                              ("vmm 256 MB chunks", 256 << 20, 0), ("vmm 64 MB chunks", 64 << 20, 0), ("vmm 2 MB chunks", 2 << 20, 0)):
+for rnd in range(int(os.environ.get("ROUNDS", "5"))):
+    methods = (("hipMalloc", -1, 0), ("vmm one handle", 0, 0), ("vmm 4 GB chunks", 4 << 30, 0), ("vmm 1 GB chunks", 1 << 30, 0),
+               ("vmm 256 MB chunks", 256 << 20, 0), ("vmm 64 MB chunks", 64 << 20, 0), ("vmm 2 MB chunks", 2 << 20, 0))
+    if os.environ.get("METHODS") == "short":
+        methods = (("hipMalloc", -1, 0), ("vmm 1 GB chunks", 1 << 30, 0), ("vmm plane-sized chunks", (npts * 8 + 4095) // 4096 * 4096, 0),
+                   ("vmm 512 MB chunks", 512 << 20, 0))
+    for how, chunk, align in methods:
         if chunk < 0:
             so2 = capi.DeviceArray(so.shape)
             so2.copy_from(so)
