@@ -18,7 +18,10 @@ Extra keys in the JSON line:
                / average launch duration measured live with HIP events on the library's stream
   cpu_baseline the oracle (C restatement of the reference, kind "port") timed on one host
                core on a bounded sample of the same workload
-Multi-GPU (N > 1): one rank per GPU under torch.distributed (RCCL); see DESIGN.md section 7.
+Multi-GPU (N > 1): one process per GPU.  Started as the driver does (torch.distributed.run sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*) every process is a rank; started bare (`python bench.py --gpus N`) the parent spawns N fresh rank
+processes before it touches a GPU itself.  The 3D workload runs without torch: halo, norms and coarse gather are RCCL
+calls issued by libcedar_amd.so (cedar_amd/comm.py).  N GPUs requested but fewer visible is an error.
 """
 import argparse
 import json
@@ -142,6 +145,41 @@ def cpu_baseline(wl, relax):
                       f"(one per host core of {cpu_model}, no halo cost charged); single rank alone: {one['dof_per_s']:.3e} DOF/s; {one['what']}"}
 
 
+def visible_gpus():
+    """number of GPUs this box shows, counted in a child process so that the caller stays free of any HIP state"""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from cedar_amd import capi; "
+                          "print(capi.device_count())" % ROOT], capture_output=True, text=True, timeout=300)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit("bench.py: could not count the GPUs: " + out.stderr[-400:])
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes (this one has not touched a GPU)"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
         cpu_worker(sys.argv[2], sys.argv[3], float(sys.argv[4]))
@@ -153,14 +191,25 @@ def main():
     ap.add_argument("--workload", default="3d27", choices=list(WORKLOADS))
     ap.add_argument("--size", type=int, default=0, help="override the per-GPU grid extent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allocations", type=int, default=3,
+                    help="N=1: fresh operator allocations the roofline launch time is the median of")
     ap.add_argument("--strong", action="store_true",
                     help="3D, N>1: keep the GLOBAL grid at --size^3 and split it over the ranks (strong scaling); "
                          "default is --size^3 per GPU (weak scaling, what the driver's scaling table uses)")
     args = ap.parse_args()
 
+    rehearsal = os.environ.get("CEDAR_AMD_DIST_BACKEND", "rccl") != "rccl"  # ranks share a GPU over a host-staged transport
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            ngpu = visible_gpus()
+            if ngpu < args.gpus and not rehearsal:
+                raise SystemExit("bench.py: %d GPUs requested, %d visible" % (args.gpus, ngpu))
+            spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     nd, n_default, relax, bytes_per_dof, launches, label = WORKLOADS[args.workload]
     relax_kernel = "relax27_plane" if nd == 3 else relax
     if world > 4 and nd == 3:  # rank grids with a y split exchange halos after every row class: four launches per sweep
@@ -168,37 +217,43 @@ def main():
     # (2 and 4 GPUs run z slabs: a whole k-parity -- the plane-fused kernel -- between two exchanges)
     n = args.size or n_default
 
-    if world > 1:
-        # torch bundles its own HIP runtime: it must be the first one loaded in a process that uses
-        # both torch.distributed and libcedar_amd.so, so that there is exactly one runtime
+    use_torch = world > 1 and nd == 2  # the 2D multi-GPU solver still runs on torch tensors (cedar_amd/dist2d.py)
+    if use_torch:
+        # torch bundles its own libamdhip64.so.7: it must be the first one mapped in a process that uses both torch
+        # and libcedar_amd.so; the 3D path below never imports torch
         import torch  # noqa: F401
     from cedar_amd import capi
-    if capi.device_count() < 1:
+    ndev = capi.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py: no GPU visible; cedar_amd has no CPU fallback")
+    if world > 1 and ndev < world and not rehearsal:
+        raise SystemExit("bench.py: %d GPUs requested, %d visible" % (world, ndev))
 
-    dist = None
+    dist, comm = None, None
     if world > 1:
+        local_rank = local_rank % ndev  # rehearsal on a one-GPU box: the ranks share the card
+    capi.set_device(local_rank)
+    if use_torch:
         import torch
         import torch.distributed as dist
-        ndev = torch.cuda.device_count()
-        local_rank = local_rank % max(ndev, 1)  # rehearsal on a one-GPU box: ranks share the card
         torch.cuda.set_device(local_rank)
-        backend = os.environ.get("CEDAR_AMD_DIST_BACKEND", "nccl")  # "gloo" only for rehearsals
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
         else:
-            dist.init_process_group(backend)
-    capi.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif world > 1:
+        from cedar_amd.comm import NativeComm, SocketComm
+        comm = SocketComm(rank, world) if rehearsal else NativeComm(rank, world)
 
     dof = float(n) ** nd
     dsolver, t_setup = None, None
     if world > 1:
         # domain decomposition: one 512^3 block per GPU of a (px,py,pz)*512 global grid (z slabs up to 4 GPUs,
         # 2x2x2 on 8 = BASELINE config 5), halo over RCCL
-        import torch
-        from cedar_amd.dist import DistSolver3, GpuBackend, Topology
-        dev = torch.device("cuda", local_rank)
+        from cedar_amd.dist import Topology
         if nd == 3:
+            from cedar_amd.dist import DistSolver3, GpuBackend
+            be = GpuBackend(comm, local_rank)
             topo = Topology(rank, world)
             ln = [n, n, n]  # local extents
             if args.strong:
@@ -206,19 +261,23 @@ def main():
                     raise SystemExit("bench.py --strong: %d does not split into even local extents over %s" % (n, topo.p))
                 ln = [n // topo.p[d] for d in range(3)]
             g = (ln[2] + 2, ln[1] + 2, ln[0] + 2)
-            A = torch.zeros((14,) + g, dtype=torch.float64, device=dev)
-            bt = torch.zeros(g, dtype=torch.float64, device=dev)
+            A = be.zeros((14,) + g)
+            bt = be.zeros(g)
             import ctypes as C
             place = [float(topo.coord[d] * ln[d]) for d in range(3)] + [float(ln[d] * topo.p[d]) for d in range(3)]
             pp = (C.c_double * 6)(*place)
-            capi.lib.cedar_amd_gallery(112, A.data_ptr(), bt.data_ptr(), ln[0], ln[1], ln[2], pp)  # fe3 placed in the global grid
+            capi.lib.cedar_amd_gallery(112, A.ptr, bt.ptr, ln[0], ln[1], ln[2], pp)  # fe3 placed in the global grid
             dof = float(ln[0]) * ln[1] * ln[2]
-            dsolver = DistSolver3(GpuBackend(dev), topo, A)
+            dsolver = DistSolver3(be, topo, A)
+            xt = be.zeros(g)
         else:
             # 2D workloads: n^2 per GPU of a (px n) x (py n) global grid, cedar_amd/dist2d.py.  The
             # synthetic operators are host generators of the whole grid: every rank builds it and keeps its block.
             import problems as pb
+            import torch
+            from cedar_amd._torch_dist import GpuBackend
             from cedar_amd.dist2d import DistSolver2, rank_grid2
+            dev = torch.device("cuda", local_rank)
             px, py = rank_grid2(world)
             if 5.0 * (px * n + 2) * (py * n + 2) * 8 > 12e9:
                 raise SystemExit("bench.py: the host generator of this 2D workload is too large for %d GPUs at %d^2 per GPU; "
@@ -233,7 +292,7 @@ def main():
             bt = torch.from_numpy(np.ascontiguousarray(gb[sl]) * m).to(dev)
             del gso, gb
             dsolver = DistSolver2(GpuBackend(dev), topo, A, relax=relax)
-        xt = torch.zeros_like(bt)
+            xt = torch.zeros_like(bt)
         so = b = x = None
 
         class _S:  # minimal adapter so that the timing code below is shared
@@ -244,13 +303,11 @@ def main():
                 return dsolver.nlev_global
 
             def time_relax(self, x_, b_, k):
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
+                from cedar_amd.comm import EventTimer
+                t = EventTimer()  # HIP events on the library's stream (the null stream torch shares in the 2D case)
                 for i in range(k):
                     dsolver._smooth(dsolver.levels[0], xt, bt, i & 1, 1)
-                ev1.record()
-                ev1.synchronize()
-                return ev0.elapsed_time(ev1)
+                return t.stop()
 
             def close(self):
                 pass
@@ -265,10 +322,12 @@ def main():
         x = capi.DeviceArray(b.shape)
 
     def barrier():
-        capi.sync()
+        capi.lib.cedar_amd_device_sync()
         if dist is not None:
             dist.barrier()
-            capi.sync()
+        elif comm is not None:
+            comm.barrier()
+        capi.lib.cedar_amd_device_sync()
 
     for _ in range(args.warmup):
         solver.vcycle(x, b)
@@ -283,12 +342,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    elif comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
 
     # dominant kernel: the level-0 relax sweep, HIP events on the library's stream
     nsw = 20 if nd == 3 else 40
     solver.time_relax(x, b, 4)
     ms = solver.time_relax(x, b, nsw)
-    launch_ms = ms / (nsw * launches)
+    per_alloc = [ms / (nsw * launches)]
+    if world == 1 and args.allocations > 1:
+        # the sweep time depends on where the operator allocation lands in HBM (7-14 % between allocations of one
+        # process, profiles/r01_allocation_placement_variance.log): quote the MEDIAN over fresh allocations of the
+        # operator + hierarchy, not the luck of the first one
+        for _ in range(args.allocations - 1):
+            so2, b2 = build_problem(capi, args.workload, n)
+            s2 = capi.Solver(so2, relax=relax, share_operator=True)
+            x2 = capi.DeviceArray(b2.shape)
+            s2.time_relax(x2, b2, 4)
+            per_alloc.append(s2.time_relax(x2, b2, nsw) / (nsw * launches))
+            s2.close()
+            so2.free(); b2.free(); x2.free()
+    launch_ms = sorted(per_alloc)[len(per_alloc) // 2]
     alg_bytes_launch = bytes_per_dof * dof / launches
     achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
     traffic = None
@@ -300,14 +374,16 @@ def main():
         pass
     roofline = {"bound": "hbm", "kernel": "relax sweep level 0 (%s)" % relax_kernel,
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes_launch}
+                "traffic": traffic, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "launch_ms_per_allocation": per_alloc,
+                "launch_ms_is": "median over %d fresh allocations of operator + hierarchy" % len(per_alloc)}
 
     if rank == 0:
         out = {
             "metric": "fine-grid DOF/s per V-cycle",
             "value": dof * world * args.steps / elapsed,
             "unit": "DOF/s",
-            "n_gpus": world,
+            "n_gpus": world,  # == --gpus (checked above)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -323,7 +399,8 @@ def main():
                        "domain decomposition %s ranks, %s per GPU, halo exchange over %s" %
                        ("x".join(map(str, topo.p[:nd])),
                         "x".join(str(int(v)) for v in ln) if nd == 3 else "%d^2" % n,
-                        "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
+                        comm.name if comm is not None else
+                        ("RCCL (torch.distributed)" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)"))},
             "roofline": roofline,
             "setup_ms": None if t_setup is None else t_setup * 1e3,  # device-side interp + Galerkin + relax set-up
         }
@@ -334,6 +411,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    elif comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -47,11 +47,43 @@ enum { LXYL = 0, LXYR = 1, LXYA = 2, LXYB = 3, LXZA = 4, LXZB = 5,
 // handles the unaligned dwordx4.
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
+// View of a 3D operator for the solve-phase kernels (27-point relax / residual): entry (slot, i, j, k) =
+// so[slot*SS + j*SJ + k*SK + i], reciprocal diagonal (SOR plane msor) = sor[j*rSJ + k*rSK + i].
+//   Cedar layout (the boundary):  SS = II*JJ*KK, SJ = II, SK = II*JJ; sor = SOR + II*JJ*KK, same strides.
+//   row-interleaved copy (solver-internal, op3_ilv): the NS3 = 16 slot-rows of grid row (j,k) are contiguous
+//   (14 operator slots, 1/diag, one pad row), rows padded to RS doubles (a multiple of 16 => every slot-row
+//   starts on a 128-byte line): SS = RS, SJ = 16*RS, SK = 16*RS*JJ, sor = so + 14*RS.
+struct Op3 {
+	const real_t *so;
+	size_t SS, SJ, SK;
+	const real_t *sor;
+	size_t rSJ, rSK;
+};
+enum { NS3 = 16, ILV_SOR = 14 };
+static inline Op3 op3_cedar(const real_t *so, const real_t *sor, int II, int JJ, int KK)
+{
+	const size_t sk = (size_t)II * JJ, PS = sk * (size_t)KK;
+	return Op3{so, PS, (size_t)II, sk, sor ? sor + PS : nullptr, (size_t)II, sk};
+}
+static inline size_t ilv_row_stride(int II) { return ((size_t)II + 15) / 16 * 16; }
+static inline size_t ilv_doubles(int II, int JJ, int KK) { return ilv_row_stride(II) * NS3 * (size_t)JJ * KK; }
+static inline Op3 op3_ilv(const real_t *a, int II, int JJ, int KK)
+{
+	const size_t RS = ilv_row_stride(II);
+	(void)KK;
+	return Op3{a, RS, NS3 * RS, NS3 * RS * (size_t)JJ, a + ILV_SOR * RS, NS3 * RS, NS3 * RS * (size_t)JJ};
+}
+// build the row-interleaved copy from the Cedar-layout operator (14 slots) and 1/diag plane (relax3d.hip)
+void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, int JJ, int KK, hipStream_t st);
+
 // ---- kernel launchers (device pointers, asynchronous on `st`) ----
 // relax3d.hip
 void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, size_t KK, hipStream_t st);
 void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                int II, int JJ, int KK, int nstncl, int updown, hipStream_t st);
+// 27-point sweep / residual on an operator view (the solver's row-interleaved copy)
+void relax3_gs27_op(const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, int KK, int updown, hipStream_t st);
+void residual27_op(const Op3 &A, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st);
 void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                      int II, int JJ, int KK, int kb, int up, int part, hipStream_t st);
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,

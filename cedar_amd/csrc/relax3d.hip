@@ -58,6 +58,27 @@ void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, 
 	hipLaunchKernelGGL(recip_kernel, dim3(grid), dim3(256), 0, st, so_diag, sor_msor, (int)II, (int)JJ, (int)KK);
 }
 
+// row-interleaved solve copy of a 27-point operator (common.h Op3): one workgroup per grid row, unit-stride both ways
+__global__ __launch_bounds__(256) void ilv_build_kernel(const real_t *__restrict__ so, const real_t *__restrict__ sor,
+                                                         real_t *__restrict__ out, int II, int JJ, int KK, size_t RS)
+{
+	const size_t row = blockIdx.x; // j + JJ*k
+	const size_t PS = (size_t)II * JJ * KK;
+	const real_t *src = so + row * (size_t)II;
+	real_t *dst = out + row * (size_t)NS3 * RS;
+	for (int s = 0; s < NS3; s++) {
+		const real_t *from = s < 14 ? src + (size_t)s * PS : (s == ILV_SOR ? sor + row * (size_t)II : nullptr);
+		for (size_t i = threadIdx.x; i < RS; i += 256)
+			dst[(size_t)s * RS + i] = (from && i < (size_t)II) ? from[i] : 0.0;
+	}
+}
+
+void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, int JJ, int KK, hipStream_t st)
+{
+	hipLaunchKernelGGL(ilv_build_kernel, dim3((unsigned)((size_t)JJ * KK)), dim3(256), 0, st, so, sor_msor, ilv, II, JJ, KK,
+	                   ilv_row_stride(II));
+}
+
 // ------------------------------------------------------------------ 27-pt
 // coefficients seen from one grid point X=(i,j,k); names = slot _ where stored
 struct C27 {
@@ -104,25 +125,27 @@ __device__ __forceinline__ real_t offdiag27(real_t qf, const C27 &c, const real_
 	return s;
 }
 
-// direct-from-memory evaluation at one point (generic path; i,j,k 0-based incl. ghost)
-__device__ __forceinline__ real_t offdiag27_mem(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                const real_t *__restrict__ q, size_t II, size_t JJ, size_t PS,
-                                                size_t x)
+// direct-from-memory evaluation at one point (generic path; x = vector offset of (i,j,k), xa = operator offset)
+__device__ __forceinline__ real_t offdiag27_mem(const Op3 &A, const real_t *__restrict__ qf,
+                                                const real_t *__restrict__ q, size_t II, size_t JJ,
+                                                size_t x, size_t xa)
 {
 	const size_t sj = II, sk = II * JJ;
+	const size_t PS = A.SS, aj = A.SJ, ak = A.SK;
+	const real_t *__restrict__ so = A.so;
 	C27 c;
-	c.pw = so[KPW * PS + x]; c.ps = so[KPS * PS + x]; c.psw = so[KPSW * PS + x];
-	c.b = so[KB * PS + x]; c.bw = so[KBW * PS + x]; c.bs = so[KBS * PS + x]; c.bsw = so[KBSW * PS + x];
-	c.pnw_n = so[KPNW * PS + x + sj]; c.ps_n = so[KPS * PS + x + sj];
-	c.bnw_n = so[KBNW * PS + x + sj]; c.bn_n = so[KBN * PS + x + sj];
-	c.b_t = so[KB * PS + x + sk]; c.be_t = so[KBE * PS + x + sk];
-	c.bn_t = so[KBN * PS + x + sk]; c.bne_t = so[KBNE * PS + x + sk];
-	c.bse_nt = so[KBSE * PS + x + sj + sk]; c.bs_nt = so[KBS * PS + x + sj + sk];
-	c.psw_ne = so[KPSW * PS + x + 1 + sj]; c.bne_ne = so[KBNE * PS + x + 1 + sj];
-	c.pw_e = so[KPW * PS + x + 1]; c.pnw_e = so[KPNW * PS + x + 1];
-	c.be_e = so[KBE * PS + x + 1]; c.bse_e = so[KBSE * PS + x + 1];
-	c.bsw_net = so[KBSW * PS + x + 1 + sj + sk];
-	c.bw_et = so[KBW * PS + x + 1 + sk]; c.bnw_et = so[KBNW * PS + x + 1 + sk];
+	c.pw = so[KPW * PS + xa]; c.ps = so[KPS * PS + xa]; c.psw = so[KPSW * PS + xa];
+	c.b = so[KB * PS + xa]; c.bw = so[KBW * PS + xa]; c.bs = so[KBS * PS + xa]; c.bsw = so[KBSW * PS + xa];
+	c.pnw_n = so[KPNW * PS + xa + aj]; c.ps_n = so[KPS * PS + xa + aj];
+	c.bnw_n = so[KBNW * PS + xa + aj]; c.bn_n = so[KBN * PS + xa + aj];
+	c.b_t = so[KB * PS + xa + ak]; c.be_t = so[KBE * PS + xa + ak];
+	c.bn_t = so[KBN * PS + xa + ak]; c.bne_t = so[KBNE * PS + xa + ak];
+	c.bse_nt = so[KBSE * PS + xa + aj + ak]; c.bs_nt = so[KBS * PS + xa + aj + ak];
+	c.psw_ne = so[KPSW * PS + xa + 1 + aj]; c.bne_ne = so[KBNE * PS + xa + 1 + aj];
+	c.pw_e = so[KPW * PS + xa + 1]; c.pnw_e = so[KPNW * PS + xa + 1];
+	c.be_e = so[KBE * PS + xa + 1]; c.bse_e = so[KBSE * PS + xa + 1];
+	c.bsw_net = so[KBSW * PS + xa + 1 + aj + ak];
+	c.bw_et = so[KBW * PS + xa + 1 + ak]; c.bnw_et = so[KBNW * PS + xa + 1 + ak];
 	real_t qq[3][3][3];
 #pragma unroll
 	for (int dk = 0; dk < 3; dk++)
@@ -135,19 +158,18 @@ __device__ __forceinline__ real_t offdiag27_mem(const real_t *__restrict__ so, c
 }
 
 // generic fallback: one colour per launch, one thread per colour point
-__global__ void relax27_colour(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                               real_t *__restrict__ q, const real_t *__restrict__ sor,
+__global__ void relax27_colour(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                int II, int JJ, int KK, int ib, int jb, int kb)
 {
 	int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
 	size_t n = (size_t)ni * nj * nk;
-	size_t PS = (size_t)II * JJ * KK;
 	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
 		int a = (int)(t % ni);
 		size_t r = t / ni;
 		int b = (int)(r % nj), c = (int)(r / nj);
-		size_t x = (size_t)(1 + ib + 2 * a) + (size_t)II * ((size_t)(1 + jb + 2 * b) + (size_t)JJ * (size_t)(1 + kb + 2 * c));
-		q[x] = offdiag27_mem(so, qf, q, II, JJ, PS, x) * sor[PS + x];
+		const size_t i = (size_t)(1 + ib + 2 * a), j = (size_t)(1 + jb + 2 * b), k = (size_t)(1 + kb + 2 * c);
+		size_t x = i + (size_t)II * (j + (size_t)JJ * k);
+		q[x] = offdiag27_mem(A, qf, q, II, JJ, x, i + j * A.SJ + k * A.SK) * A.sor[i + j * A.rSJ + k * A.rSK];
 	}
 }
 
@@ -184,17 +206,25 @@ __device__ __forceinline__ void ldpair_so(const real_t *__restrict__ p, bool two
 //         relax pass keeps them cacheable so that the second task finds them in L2 / Infinity Cache;
 //   NTO = the task's own row (offset 0) where that is its LAST use in the launch (residual: the rows at
 //         j+1 / k+1 are read again by the neighbouring task, the own row is not).
-template <bool NT, bool NTP = NT, bool NTO = NT>
-__device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                            const real_t *__restrict__ q, size_t row, size_t sj, size_t sk, size_t PS,
+// WI ("what if", experiments only, results wrong): bit 0 = every q row read from the task's own row, bit 1 = the
+// slot-rows of plane k+1 read from plane k, bit 2 = every inter-plane slot read from KPW -- the loads then hit
+// the caches and the timing shows what removing that traffic would be worth.
+#define WI_SLOT(slot) ((size_t)(((WI & 4) && ((slot) == KB || (slot) >= KBW)) ? KPW : (slot)))
+template <bool NT, bool NTP = NT, bool NTO = NT, int WI = 0>
+__device__ __forceinline__ void load_pair27(const Op3 &A, const real_t *__restrict__ qf,
+                                            const real_t *__restrict__ q, size_t rowA, size_t row, size_t sj, size_t sk,
                                             int ie, int io, bool two, C27 &ce, C27 &co,
                                             real_t (&qe)[3][3][3], real_t (&qo)[3][3][3], real_t &qfe, real_t &qfo)
 {
+	// operator entry (slot, i, j+dj, k+dk) = A.so[slot*A.SS + rowA + dj*A.SJ + dk*A.SK + i]; vectors use row, sj, sk
+	const real_t *__restrict__ so = A.so;
+	const size_t PS = A.SS, aj = A.SJ, ak = (WI & 2) ? 0 : A.SK;
+	if (WI & 1) { sj = 0; sk = 0; }
 	// ---- [i]-pattern streams: (value at ie, value at io)
 #define LD_I_(N, slot, off, fe, fo)                                                    \
 {                                                                                  \
 	real_t a_, b_;                                                                 \
-	ldpair_so<N>(so + (size_t)(slot)*PS + row + (off) + ie, true, a_, b_);         \
+	ldpair_so<N>(so + WI_SLOT(slot)*PS + rowA + (off) + ie, true, a_, b_);         \
 	ce.fe = a_; co.fo = b_;                                                        \
 }
 #define LD_I(slot, off, fe, fo) LD_I_(NT, slot, off, fe, fo)
@@ -203,9 +233,9 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 #define LD_ISO(slot, fe, fo) LD_I_((NTP && NTO), slot, 0, fe, fo)
 	LD_IO(KPW, pw, pw) LD_ISO(KPS, ps, ps) LD_ISO(KPSW, psw, psw) LD_IO(KB, b, b)
 	LD_IO(KBW, bw, bw) LD_IO(KBS, bs, bs) LD_IO(KBSW, bsw, bsw)
-	LD_IS(KPNW, sj, pnw_n, pnw_n) LD_IS(KPS, sj, ps_n, ps_n) LD_I(KBNW, sj, bnw_n, bnw_n) LD_I(KBN, sj, bn_n, bn_n)
-	LD_I(KB, sk, b_t, b_t) LD_I(KBE, sk, be_t, be_t) LD_I(KBN, sk, bn_t, bn_t) LD_I(KBNE, sk, bne_t, bne_t)
-	LD_I(KBSE, sj + sk, bse_nt, bse_nt) LD_I(KBS, sj + sk, bs_nt, bs_nt)
+	LD_IS(KPNW, aj, pnw_n, pnw_n) LD_IS(KPS, aj, ps_n, ps_n) LD_I(KBNW, aj, bnw_n, bnw_n) LD_I(KBN, aj, bn_n, bn_n)
+	LD_I(KB, ak, b_t, b_t) LD_I(KBE, ak, be_t, be_t) LD_I(KBN, ak, bn_t, bn_t) LD_I(KBNE, ak, bne_t, bne_t)
+	LD_I(KBSE, aj + ak, bse_nt, bse_nt) LD_I(KBS, aj + ak, bs_nt, bs_nt)
 #undef LD_I
 #undef LD_IO
 #undef LD_IS
@@ -215,17 +245,17 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 #define LD_IP_(N, slot, off, f)                                                        \
 {                                                                                  \
 	real_t a_, b_;                                                                 \
-	ldpair_so<N>(so + (size_t)(slot)*PS + row + (off) + io, two, a_, b_);          \
+	ldpair_so<N>(so + WI_SLOT(slot)*PS + rowA + (off) + io, two, a_, b_);          \
 	ce.f = a_; co.f = b_;                                                          \
 }
 #define LD_IP(slot, off, f) LD_IP_(NT, slot, off, f)
 #define LD_IPO(slot, f) LD_IP_(NTO, slot, 0, f)
 #define LD_IPS(slot, off, f) LD_IP_(NTP, slot, off, f)
 #define LD_IPSO(slot, f) LD_IP_((NTP && NTO), slot, 0, f)
-	LD_IPS(KPSW, sj, psw_ne) LD_IP(KBNE, sj, bne_ne)
+	LD_IPS(KPSW, aj, psw_ne) LD_IP(KBNE, aj, bne_ne)
 	LD_IPO(KPW, pw_e) LD_IPSO(KPNW, pnw_e) LD_IPO(KBE, be_e) LD_IPO(KBSE, bse_e)
-	LD_IP(KBSW, sj + sk, bsw_net)
-	LD_IP(KBW, sk, bw_et) LD_IP(KBNW, sk, bnw_et)
+	LD_IP(KBSW, aj + ak, bsw_net)
+	LD_IP(KBW, ak, bw_et) LD_IP(KBNW, ak, bnw_et)
 #undef LD_IP
 #undef LD_IPO
 #undef LD_IPS
@@ -254,11 +284,12 @@ __device__ __forceinline__ void load_pair27(const real_t *__restrict__ so, const
 // the workgroup must call it (one __syncthreads inside).
 //   EFIRST = true : colour with even 1-based i (i = 2,4,..) first  (UP order)
 //   EFIRST = false: odd i first                                     (DOWN order)
-template <int BS, bool EFIRST, bool NT, bool NTP = NT>
-__device__ __forceinline__ void relax27_row_task(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                 real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                 int II, size_t sj, size_t sk, size_t PS, size_t row, real_t *xch)
+template <int BS, bool EFIRST, bool NT, bool NTP = NT, int WI = 0>
+__device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__restrict__ qf,
+                                                 real_t *__restrict__ q, int II, size_t sj, size_t sk,
+                                                 size_t j, size_t k, real_t *xch)
 {
+	const size_t row = j * sj + k * sk, rowA = j * A.SJ + k * A.SK;
 	const int p = threadIdx.x;
 	const int ie = 2 * p + 1, io = 2 * p + 2;     // 0-based offsets of the pair in the row
 	const bool e_ok = ie <= II - 2;                // interior?
@@ -271,9 +302,9 @@ __device__ __forceinline__ void relax27_row_task(const real_t *__restrict__ so, 
 	real_t qfe = 0, qfo = 0, sre = 0, sro = 0;
 
 	if (e_ok) {
-		load_pair27<NT, NTP>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		load_pair27<NT, NTP, NT, WI>(A, qf, q, rowA, row, sj, sk, ie, io, two, ce, co, qe, qo, qfe, qfo);
 		real_t a_, b_;
-		ldpair(sor + PS + row + ie, true, a_, b_); sre = a_; sro = b_;
+		ldpair(A.sor + j * A.rSJ + k * A.rSK + ie, true, a_, b_); sre = a_; sro = b_;
 	}
 
 	if (EFIRST) {
@@ -312,8 +343,8 @@ __device__ __forceinline__ void relax27_row_task(const real_t *__restrict__ so, 
 // fast path: one workgroup = one grid row, both i-colours.  Rows j = j0 + jstep*jr, jr < nrj, of the
 // planes k = 1 + kb + 2*(kr + kr0), kr < nrk.
 template <int BS, bool EFIRST, bool NT>
-__global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                    real_t *__restrict__ q, const real_t *__restrict__ sor,
+__global__ __launch_bounds__(BS) void relax27_rows(const Op3 A, const real_t *__restrict__ qf,
+                                                    real_t *__restrict__ q,
                                                     int II, int JJ, int KK, int j0, int jstep, int kb, int nrj, int nrk,
                                                     TileShape ts, int kr0)
 {
@@ -323,8 +354,8 @@ __global__ __launch_bounds__(BS) void relax27_rows(const real_t *__restrict__ so
 	unsigned jr, kr;
 	if (L >= nblk || !tile_rows(L, (unsigned)nrj, (unsigned)nrk, ts, jr, kr)) return; // whole workgroup leaves together
 	const size_t j = (size_t)(j0 + jstep * (int)jr), k = (size_t)(1 + kb + 2 * ((int)kr + kr0)); // 0-based incl. ghost
-	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
-	relax27_row_task<BS, EFIRST, NT>(so, qf, q, sor, II, sj, sk, PS, j * sj + k * sk, xch);
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
+	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, j, k, xch);
 }
 
 // The shell of a row class (rows next to a face shared with another rank) is up to four thin rectangles of
@@ -335,8 +366,8 @@ struct ShellRects {
 };
 
 template <int BS, bool EFIRST, bool NT>
-__global__ __launch_bounds__(BS) void relax27_rows_shell(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                          real_t *__restrict__ q, const real_t *__restrict__ sor,
+__global__ __launch_bounds__(BS) void relax27_rows_shell(const Op3 A, const real_t *__restrict__ qf,
+                                                          real_t *__restrict__ q,
                                                           int II, int JJ, int KK, int kb, ShellRects rc)
 {
 	__shared__ real_t xch[BS + 2];
@@ -347,8 +378,8 @@ __global__ __launch_bounds__(BS) void relax27_rows_shell(const real_t *__restric
 		if (t < rc.n && b >= rc.start[t]) r = t;
 	const int w = b - rc.start[r];
 	const size_t j = (size_t)(rc.j0[r] + 2 * (w % rc.nrj[r])), k = (size_t)(1 + kb + 2 * (rc.kr0[r] + w / rc.nrj[r]));
-	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
-	relax27_row_task<BS, EFIRST, NT>(so, qf, q, sor, II, sj, sk, PS, j * sj + k * sk, xch);
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
+	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, j, k, xch);
 }
 
 // Plane-fused pass: both row classes of the planes of one k-parity in ONE launch.  In a plane the
@@ -362,9 +393,9 @@ __global__ __launch_bounds__(BS) void relax27_rows_shell(const real_t *__restric
 // neighbours in different workgroups: it is left to a small second launch (relax27_rows over those
 // rows, j0 = first such row, jstep = 2*frun).  Same arithmetic per point, same values read =>
 // results identical to the four-launch order.
-template <int BS, bool EFIRST, bool NT>
-__global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                     real_t *__restrict__ q, const real_t *__restrict__ sor,
+template <int BS, bool EFIRST, bool NT, int WI = 0>
+__global__ __launch_bounds__(BS) void relax27_plane(const Op3 A, const real_t *__restrict__ qf,
+                                                     real_t *__restrict__ q,
                                                      int II, int JJ, int KK, int jbF, int kb, int nrk, int frun, int nrun,
                                                      int kr0)
 {
@@ -375,12 +406,12 @@ __global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ s
 	const int kr = (int)(L / (unsigned)nrun), run = (int)(L % (unsigned)nrun);
 	const int nF = (JJ - 2 - jbF + 1) / 2, nS = (JJ - 2 - (1 - jbF) + 1) / 2;
 	const int f0 = run * frun, f1 = min(nF, f0 + frun);
-	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
-	const size_t plane = (size_t)(1 + kb + 2 * (kr + kr0)) * sk; // planes kr0 .. kr0+nrk-1 of parity kb
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
+	const size_t k = (size_t)(1 + kb + 2 * (kr + kr0)); // planes kr0 .. kr0+nrk-1 of parity kb
 	int t = 0;
 	for (int f = f0; f < f1; f++) {
 		// F row f: j = 1 + jbF + 2 f
-		relax27_row_task<BS, EFIRST, NT, false>(so, qf, q, sor, II, sj, sk, PS, plane + (size_t)(1 + jbF + 2 * f) * sj, xch[t & 1]);
+		relax27_row_task<BS, EFIRST, NT, false, WI>(A, qf, q, II, sj, sk, (size_t)(1 + jbF + 2 * f), k, xch[t & 1]);
 		t++;
 		// the S row both of whose F neighbours are now done (a missing neighbour = ghost row):
 		//   jbF = 0: S row g (j = 2+2g) lies between F rows g, g+1  -> after F(f): g = f-1 (f > f0)
@@ -389,7 +420,7 @@ __global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ s
 		const bool have = jbF ? (f > f0 || f == 0) : (f > f0);
 		if (have && g >= 0 && g < nS) {
 			__syncthreads(); // F stores of every wave visible before the S loads
-			relax27_row_task<BS, EFIRST, NT, false>(so, qf, q, sor, II, sj, sk, PS, plane + (size_t)(2 - jbF + 2 * g) * sj, xch[t & 1]);
+			relax27_row_task<BS, EFIRST, NT, false, WI>(A, qf, q, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, xch[t & 1]);
 			t++;
 		}
 	}
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(BS) void relax27_plane(const real_t *__restrict__ s
 			// jbF = 0: g = nF-1 was not reached in the loop (needs F(nF) which does not exist)
 			// jbF = 1: g = nF    likewise
 			__syncthreads();
-			relax27_row_task<BS, EFIRST, NT, false>(so, qf, q, sor, II, sj, sk, PS, plane + (size_t)(2 - jbF + 2 * g) * sj, xch[t & 1]);
+			relax27_row_task<BS, EFIRST, NT, false, WI>(A, qf, q, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, xch[t & 1]);
 		}
 	}
 }
@@ -436,7 +467,7 @@ __global__ void relax7_colour(const real_t *__restrict__ so, const real_t *__res
 // (2p+1, 2p+2) of its row, every stream is read with 16-byte loads, one 16-byte store.
 // (BMG3_SymStd_residual.f90:77-104; bit-identical term order.)
 template <int BS, bool NT>
-__global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+__global__ __launch_bounds__(BS) void residual27_rows(const Op3 A, const real_t *__restrict__ qf,
                                                        const real_t *__restrict__ q, real_t *__restrict__ res,
                                                        int II, int JJ, int KK, unsigned nblk, TileShape ts)
 {
@@ -444,8 +475,8 @@ __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__
 	unsigned jr, kr;
 	if (L >= nblk || !tile_rows(L, (unsigned)(JJ - 2), (unsigned)(KK - 2), ts, jr, kr)) return;
 	const size_t j = (size_t)jr + 1, k = (size_t)kr + 1;
-	const size_t sj = (size_t)II, sk = (size_t)II * JJ, PS = sk * (size_t)KK;
-	const size_t row = j * sj + k * sk;
+	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
+	const size_t row = j * sj + k * sk, rowA = j * A.SJ + k * A.SK;
 	for (int p = threadIdx.x; 2 * p + 1 <= II - 2; p += BS) {
 		const int ie = 2 * p + 1, io = 2 * p + 2;
 		const bool o_ok = io <= II - 2, two = io + 1 <= II - 1;
@@ -453,8 +484,8 @@ __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__
 		real_t qe[3][3][3], qo[3][3][3], qfe, qfo, de, dn;
 		// NT: the own row's operator entries are streamed (last use in this launch), the rows at j+1 / k+1
 		// stay cacheable for the neighbouring task that reads them as its own
-		load_pair27<false, false, NT>(so, qf, q, row, sj, sk, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
-		ldpair_so<NT>(so + row + ie, true, de, dn); // KP plane
+		load_pair27<false, false, NT>(A, qf, q, rowA, row, sj, sk, ie, io, two, ce, co, qe, qo, qfe, qfo);
+		ldpair_so<NT>(A.so + rowA + ie, true, de, dn); // KP plane
 		const real_t re = offdiag27(qfe, ce, qe) - de * qe[1][1][1];
 		if (o_ok) {
 			const real_t ro = offdiag27(qfo, co, qo) - dn * qo[1][1][1];
@@ -465,8 +496,9 @@ __global__ __launch_bounds__(BS) void residual27_rows(const real_t *__restrict__
 	}
 }
 
-void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st)
+void residual27_op(const Op3 &A, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st)
 {
+	const Op3 so = A;
 	const TileShape ts = tile_shape_resid();
 	unsigned nrows = tile_blocks((unsigned)(JJ - 2), (unsigned)(KK - 2), ts);
 	const int npairs = (II - 2 + 1) / 2;
@@ -476,6 +508,11 @@ void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t
 	else if (npairs <= 128) hipLaunchKernelGGL((residual27_rows<128, false>), dim3(xcd_grid(nrows)), dim3(128), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 	else if (nt) hipLaunchKernelGGL((residual27_rows<256, true>), dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
 	else hipLaunchKernelGGL((residual27_rows<256, false>), dim3(xcd_grid(nrows)), dim3(256), 0, st, so, qf, q, res, II, JJ, KK, nrows, ts);
+}
+
+void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st)
+{
+	residual27_op(op3_cedar(so, nullptr, II, JJ, KK), qf, q, res, II, JJ, KK, st);
 }
 
 static inline unsigned cap_grid(size_t n, unsigned bs)
@@ -488,7 +525,7 @@ static inline unsigned cap_grid(size_t n, unsigned bs)
 
 // rows j = j0 + jstep*jr (jr < nrj) of the planes kr0 .. kr0+nrk-1 (in units of planes of parity kb)
 template <int BS>
-static void launch_rows_at(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+static void launch_rows_at(bool efirst, const Op3 &A, const real_t *qf, real_t *q,
                            int II, int JJ, int KK, int j0, int jstep, int nrj, int kb, int nrk, hipStream_t st, int kr0 = 0)
 {
 	if (nrj <= 0 || nrk <= 0) return;
@@ -497,26 +534,26 @@ static void launch_rows_at(bool efirst, const real_t *so, const real_t *qf, real
 	// non-temporal operator loads: measured -1.8 % per launch at 512^3 (profiles/r01_experiment_nt_loads.log)
 	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
 	if (efirst) {
-		if (nt) hipLaunchKernelGGL((relax27_rows<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
-		else hipLaunchKernelGGL((relax27_rows<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
+		if (nt) hipLaunchKernelGGL((relax27_rows<BS, true, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
+		else hipLaunchKernelGGL((relax27_rows<BS, true, false>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
 	} else {
-		if (nt) hipLaunchKernelGGL((relax27_rows<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
-		else hipLaunchKernelGGL((relax27_rows<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
+		if (nt) hipLaunchKernelGGL((relax27_rows<BS, false, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
+		else hipLaunchKernelGGL((relax27_rows<BS, false, false>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
 	}
 }
 
 // the rows of class (jb,kb)
 template <int BS>
-static void launch_rows(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+static void launch_rows(bool efirst, const Op3 &A, const real_t *qf, real_t *q,
                         int II, int JJ, int KK, int jb, int kb, hipStream_t st)
 {
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, (JJ - 2 - jb + 1) / 2, kb, (KK - 2 - kb + 1) / 2, st);
+	launch_rows_at<BS>(efirst, A, qf, q, II, JJ, KK, 1 + jb, 2, (JJ - 2 - jb + 1) / 2, kb, (KK - 2 - kb + 1) / 2, st);
 }
 
 // plane-fused pass over the planes of parity kb: F rows (parity jbF) and the S rows between them in
 // one launch, the S rows between two workgroups' runs in a second small one (see relax27_plane)
 template <int BS>
-static void launch_plane(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+static void launch_plane(bool efirst, const Op3 &A, const real_t *qf, real_t *q,
                          int II, int JJ, int KK, int jbF, int kb, int frun, hipStream_t st, int kr0 = 0, int nrk_sub = -1)
 {
 	const int nF = (JJ - 2 - jbF + 1) / 2;
@@ -525,15 +562,30 @@ static void launch_plane(bool efirst, const real_t *so, const real_t *qf, real_t
 	const int nrun = (nF + frun - 1) / frun;
 	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
 	const unsigned grid = xcd_grid((unsigned)nrk * (unsigned)nrun);
+	if (BS == 256) { // experiments: CEDAR_AMD_WHATIF=1..7 (see load_pair27), plane-fused launch only
+		const char *ew = getenv("CEDAR_AMD_WHATIF");
+		const int wi = ew ? atoi(ew) : 0;
+#define WI_CASE(W)                                                                                                          \
+	case W:                                                                                                                 \
+		if (efirst) hipLaunchKernelGGL((relax27_plane<256, true, true, W>), dim3(grid), dim3(256), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0); \
+		else hipLaunchKernelGGL((relax27_plane<256, false, true, W>), dim3(grid), dim3(256), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);      \
+		break;
+		if (wi) {
+			switch (wi) { WI_CASE(1) WI_CASE(2) WI_CASE(3) WI_CASE(4) WI_CASE(5) default: break; }
+			launch_rows_at<BS>(efirst, A, qf, q, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st, kr0);
+			return;
+		}
+#undef WI_CASE
+	}
 	if (efirst) {
-		if (nt) hipLaunchKernelGGL((relax27_plane<BS, true, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
-		else hipLaunchKernelGGL((relax27_plane<BS, true, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
+		if (nt) hipLaunchKernelGGL((relax27_plane<BS, true, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
+		else hipLaunchKernelGGL((relax27_plane<BS, true, false>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
 	} else {
-		if (nt) hipLaunchKernelGGL((relax27_plane<BS, false, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
-		else hipLaunchKernelGGL((relax27_plane<BS, false, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
+		if (nt) hipLaunchKernelGGL((relax27_plane<BS, false, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
+		else hipLaunchKernelGGL((relax27_plane<BS, false, false>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);
 	}
 	// S rows between runs: jbF = 0: j = 2 frun (r+1); jbF = 1: j = 1 + 2 frun (r+1), r = 0 .. nrun-2
-	launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st, kr0);
+	launch_rows_at<BS>(efirst, A, qf, q, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st, kr0);
 }
 
 // F rows per workgroup of the plane-fused pass; 0 = four launches per sweep (one per row class).
@@ -560,13 +612,13 @@ static int plane_frun(int JJ)
 // sides: which faces of the box have a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z); rows next to a face
 // without one read no exchanged ghost and count as interior.
 template <int BS>
-static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+static void launch_part(bool efirst, const Op3 &A, const real_t *qf, real_t *q,
                         int II, int JJ, int KK, int jb, int kb, int part, int sides, hipStream_t st)
 {
 	const int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
 	if (nrj <= 0 || nrk <= 0) return;
 	if (part == 0) {
-		launch_rows<BS>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+		launch_rows<BS>(efirst, A, qf, q, II, JJ, KK, jb, kb, st);
 		return;
 	}
 	// class rows j = 1+jb+2 jr (0-based incl. ghost): j = 1 is in the class iff jb = 0, j = ny iff it has the class parity
@@ -575,11 +627,11 @@ static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t 
 	const int khi = (1 + kb + 2 * (nrk - 1) == KK - 2 && (sides & 8)) ? nrk - 1 : nrk;
 	const int nji = jhi - jlo > 0 ? jhi - jlo : 0, nki = khi - klo > 0 ? khi - klo : 0;
 	if (part == 1) {
-		launch_rows_at<BS>(efirst, so, qf, q, sor, II, JJ, KK, 1 + jb + 2 * jlo, 2, nji, kb, nki, st, klo);
+		launch_rows_at<BS>(efirst, A, qf, q, II, JJ, KK, 1 + jb + 2 * jlo, 2, nji, kb, nki, st, klo);
 		return;
 	}
 	if (nji == 0 || nki == 0) { // no interior: the shell is the whole class
-		launch_rows<BS>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, st);
+		launch_rows<BS>(efirst, A, qf, q, II, JJ, KK, jb, kb, st);
 		return;
 	}
 	// shell = planes below klo / from khi (all rows), and in the planes between: rows below jlo / from jhi
@@ -601,24 +653,25 @@ static void launch_part(bool efirst, const real_t *so, const real_t *qf, real_t 
 	static const bool nt = getenv("CEDAR_AMD_NT") ? atoi(getenv("CEDAR_AMD_NT")) != 0 : true;
 	const dim3 grid((unsigned)rc.start[rc.n]);
 	if (efirst) {
-		if (nt) hipLaunchKernelGGL((relax27_rows_shell<BS, true, true>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
-		else hipLaunchKernelGGL((relax27_rows_shell<BS, true, false>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
+		if (nt) hipLaunchKernelGGL((relax27_rows_shell<BS, true, true>), grid, dim3(BS), 0, st, A, qf, q, II, JJ, KK, kb, rc);
+		else hipLaunchKernelGGL((relax27_rows_shell<BS, true, false>), grid, dim3(BS), 0, st, A, qf, q, II, JJ, KK, kb, rc);
 	} else {
-		if (nt) hipLaunchKernelGGL((relax27_rows_shell<BS, false, true>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
-		else hipLaunchKernelGGL((relax27_rows_shell<BS, false, false>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, KK, kb, rc);
+		if (nt) hipLaunchKernelGGL((relax27_rows_shell<BS, false, true>), grid, dim3(BS), 0, st, A, qf, q, II, JJ, KK, kb, rc);
+		else hipLaunchKernelGGL((relax27_rows_shell<BS, false, false>), grid, dim3(BS), 0, st, A, qf, q, II, JJ, KK, kb, rc);
 	}
 }
 
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                    int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part_sides)
 {
+	const Op3 A = op3_cedar(so, sor, II, JJ, KK);
 	// part_sides = part | sides << 4 (include/cedar_amd.h); no side bit set = every face has a neighbour
 	const int part = part_sides & 3, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	const int npairs = (II - 2 + 1) / 2;
-	if (npairs <= 64) launch_part<64>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
-	else if (npairs <= 128) launch_part<128>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
-	else if (npairs <= 256) launch_part<256>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
-	else if (npairs <= 512) launch_part<512>(efirst, so, qf, q, sor, II, JJ, KK, jb, kb, part, sides, st);
+	if (npairs <= 64) launch_part<64>(efirst, A, qf, q, II, JJ, KK, jb, kb, part, sides, st);
+	else if (npairs <= 128) launch_part<128>(efirst, A, qf, q, II, JJ, KK, jb, kb, part, sides, st);
+	else if (npairs <= 256) launch_part<256>(efirst, A, qf, q, II, JJ, KK, jb, kb, part, sides, st);
+	else if (npairs <= 512) launch_part<512>(efirst, A, qf, q, II, JJ, KK, jb, kb, part, sides, st);
 	else {
 		if (part == 1) return; // rows too long for the row kernel: everything goes with the shell
 		for (int c = 0; c < 2; c++) {
@@ -626,31 +679,31 @@ void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *
 			int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
 			if (ni <= 0 || nj <= 0 || nk <= 0) continue;
 			hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nk, 256)), dim3(256), 0, st,
-			                   so, qf, q, sor, II, JJ, KK, ib, jb, kb);
+			                   A, qf, q, II, JJ, KK, ib, jb, kb);
 		}
 	}
 }
 
 // recompute the points of column `icol` (0-based incl. ghost) in the rows of class (jb,kb):
 // used after a halo update of the neighbouring first-colour column (distributed runs)
-__global__ void relax27_column(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                               real_t *__restrict__ q, const real_t *__restrict__ sor,
+__global__ void relax27_column(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                int II, int JJ, int KK, int icol, int jb, int kb)
 {
 	int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
 	int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nj * nk) return;
-	size_t PS = (size_t)II * JJ * KK;
-	size_t x = (size_t)icol + (size_t)II * ((size_t)(1 + jb + 2 * (t % nj)) + (size_t)JJ * (size_t)(1 + kb + 2 * (t / nj)));
-	q[x] = offdiag27_mem(so, qf, q, II, JJ, PS, x) * sor[PS + x];
+	const size_t i = (size_t)icol, j = (size_t)(1 + jb + 2 * (t % nj)), k = (size_t)(1 + kb + 2 * (t / nj));
+	size_t x = i + (size_t)II * (j + (size_t)JJ * k);
+	q[x] = offdiag27_mem(A, qf, q, II, JJ, x, i + j * A.SJ + k * A.SK) * A.sor[i + j * A.rSJ + k * A.rSK];
 }
 
 void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                     int II, int JJ, int KK, int icol, int jb, int kb, hipStream_t st)
 {
+	const Op3 A = op3_cedar(so, sor, II, JJ, KK);
 	int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
 	if (nj <= 0 || nk <= 0) return;
-	hipLaunchKernelGGL(relax27_column, dim3((nj * nk + 127) / 128), dim3(128), 0, st, so, qf, q, sor, II, JJ, KK, icol, jb, kb);
+	hipLaunchKernelGGL(relax27_column, dim3((nj * nk + 127) / 128), dim3(128), 0, st, A, qf, q, II, JJ, KK, icol, jb, kb);
 }
 
 void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
@@ -665,7 +718,7 @@ void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t 
 // the second row class needs nothing from another rank.  part: 0 all planes of the parity, 1 = those
 // with both k-neighbours owned (they read no ghost plane), 2 = the first / last owned plane.
 template <int BS>
-static void planes_bs(bool up, const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+static void planes_bs(bool up, const Op3 &A, const real_t *qf, real_t *q,
                       int II, int JJ, int KK, int kb, int kr0, int nrk, hipStream_t st)
 {
 	if (nrk <= 0) return;
@@ -675,18 +728,19 @@ static void planes_bs(bool up, const real_t *so, const real_t *qf, real_t *q, co
 	// would occupy a fraction of the CUs for eight row tasks in a row -- such pieces take the row kernels
 	const int nF = (JJ - 2 - jbF + 1) / 2;
 	if (frun > 0 && (size_t)nrk * (size_t)((nF + frun - 1) / frun) >= 256) {
-		launch_plane<BS>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st, kr0, nrk);
+		launch_plane<BS>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st, kr0, nrk);
 		return;
 	}
 	for (int c = 0; c < 2; c++) {
 		const int jb = c == 0 ? jbF : 1 - jbF;
-		launch_rows_at<BS>(up, so, qf, q, sor, II, JJ, KK, 1 + jb, 2, (JJ - 2 - jb + 1) / 2, kb, nrk, st, kr0);
+		launch_rows_at<BS>(up, A, qf, q, II, JJ, KK, 1 + jb, 2, (JJ - 2 - jb + 1) / 2, kb, nrk, st, kr0);
 	}
 }
 
 void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                      int II, int JJ, int KK, int kb, int up, int part_sides, hipStream_t st)
 {
+	const Op3 A = op3_cedar(so, sor, II, JJ, KK);
 	const int part = part_sides & 3, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	const int nrk = (KK - 2 - kb + 1) / 2;
 	if (II < 3 || JJ < 3 || nrk <= 0) return;
@@ -700,19 +754,58 @@ void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t
 	else if (part == 2 && nki > 0) { pieces[0][0] = 0; pieces[0][1] = klo; pieces[1][0] = khi; pieces[1][1] = nrk - khi; }
 	for (auto &pc : pieces) {
 		if (pc[1] <= 0) continue;
-		if (npairs <= 64) planes_bs<64>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
-		else if (npairs <= 128) planes_bs<128>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
-		else if (npairs <= 256) planes_bs<256>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
-		else if (npairs <= 512) planes_bs<512>(up, so, qf, q, sor, II, JJ, KK, kb, pc[0], pc[1], st);
+		if (npairs <= 64) planes_bs<64>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (npairs <= 128) planes_bs<128>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (npairs <= 256) planes_bs<256>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);
+		else if (npairs <= 512) planes_bs<512>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);
 		else if (part != 1) { // rows too long for the row kernels: whole colours, everything with the shell
 			for (int c = 0; c < 4; c++) {
 				const int jb = (c >> 1) == 0 ? (up ? 0 : 1) : (up ? 1 : 0), ib = (c & 1) == 0 ? (up ? 0 : 1) : (up ? 1 : 0);
 				int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2;
 				if (ni <= 0 || nj <= 0) continue;
 				hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nrk, 256)), dim3(256), 0, st,
-				                   so, qf, q, sor, II, JJ, KK, ib, jb, kb);
+				                   A, qf, q, II, JJ, KK, ib, jb, kb);
 			}
 			break;
+		}
+	}
+}
+
+void relax3_gs27_op(const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, int KK, int updown, hipStream_t st)
+{
+	if (II < 3 || JJ < 3 || KK < 3) return;
+	{
+		const bool up = (updown == BMG_UP);
+		const int npairs = (II - 2 + 1) / 2;
+		const int frun = plane_frun(JJ);
+		if (npairs <= 512 && frun > 0) {
+			// plane-fused: UP planes of parity 0 then 1, in a plane j-parity 0 rows first; DOWN the reverse
+			for (int c = 0; c < 2; c++) {
+				const int kb = up ? c : 1 - c, jbF = up ? 0 : 1;
+				if (npairs <= 64) launch_plane<64>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
+				else if (npairs <= 128) launch_plane<128>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
+				else if (npairs <= 256) launch_plane<256>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
+				else launch_plane<512>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
+			}
+		} else if (npairs <= 512) {
+			// colour pairs in sweep order: UP (j,k) parities 00,10,01,11 with even-i first
+			for (int c = 0; c < 4; c++) {
+				int cc = up ? c : 3 - c;
+				int jb = cc & 1, kb = cc >> 1;
+				if (npairs <= 64) launch_rows<64>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+				else if (npairs <= 128) launch_rows<128>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+				else if (npairs <= 256) launch_rows<256>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+				else launch_rows<512>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+			}
+		} else {
+			for (int c = 0; c < 8; c++) {
+				int pts = up ? c : 7 - c;
+				int ib = pts & 1, jb = (pts >> 1) & 1, kb = (pts >> 2) & 1;
+				int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+				if (ni <= 0 || nj <= 0 || nk <= 0) continue;
+				hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nk, 256)), dim3(256), 0, st,
+				                   A, qf, q, II, JJ, KK, ib, jb, kb);
+			}
 		}
 	}
 }
@@ -722,38 +815,7 @@ void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 {
 	if (II < 3 || JJ < 3 || KK < 3) return;
 	if (nstncl == 14) {
-		const bool up = (updown == BMG_UP);
-		const int npairs = (II - 2 + 1) / 2;
-		const int frun = plane_frun(JJ);
-		if (npairs <= 512 && frun > 0) {
-			// plane-fused: UP planes of parity 0 then 1, in a plane j-parity 0 rows first; DOWN the reverse
-			for (int c = 0; c < 2; c++) {
-				const int kb = up ? c : 1 - c, jbF = up ? 0 : 1;
-				if (npairs <= 64) launch_plane<64>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
-				else if (npairs <= 128) launch_plane<128>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
-				else if (npairs <= 256) launch_plane<256>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
-				else launch_plane<512>(up, so, qf, q, sor, II, JJ, KK, jbF, kb, frun, st);
-			}
-		} else if (npairs <= 512) {
-			// colour pairs in sweep order: UP (j,k) parities 00,10,01,11 with even-i first
-			for (int c = 0; c < 4; c++) {
-				int cc = up ? c : 3 - c;
-				int jb = cc & 1, kb = cc >> 1;
-				if (npairs <= 64) launch_rows<64>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-				else if (npairs <= 128) launch_rows<128>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-				else if (npairs <= 256) launch_rows<256>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-				else launch_rows<512>(up, so, qf, q, sor, II, JJ, KK, jb, kb, st);
-			}
-		} else {
-			for (int c = 0; c < 8; c++) {
-				int pts = up ? c : 7 - c;
-				int ib = pts & 1, jb = (pts >> 1) & 1, kb = (pts >> 2) & 1;
-				int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
-				if (ni <= 0 || nj <= 0 || nk <= 0) continue;
-				hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nk, 256)), dim3(256), 0, st,
-				                   so, qf, q, sor, II, JJ, KK, ib, jb, kb);
-			}
-		}
+		relax3_gs27_op(op3_cedar(so, sor, II, JJ, KK), qf, q, II, JJ, KK, updown, st);
 	} else {
 		// 7-point: UP = colours 0,1; DOWN = 1,0 (:144-153)
 		for (int c = 0; c < 2; c++) {

@@ -36,7 +36,16 @@ struct Level {
 	// right-hand side, scratch for the transposed x; bt_fresh: bt holds the transpose of this visit's b
 	real_t *At = nullptr, *bt = nullptr, *xt = nullptr;
 	mutable bool bt_fresh = false;
+	// 3D 27-point: row-interleaved solve copy of A and 1/diag (common.h Op3) read by relax and residual
+	real_t *Ailv = nullptr;
 };
+
+real_t *dalloc_raw(size_t n) // not cleared: the caller writes every element
+{
+	void *p = nullptr;
+	CEDAR_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(real_t)));
+	return static_cast<real_t *>(p);
+}
 
 real_t *dalloc(size_t n)
 {
@@ -109,9 +118,36 @@ void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, 
 	}
 }
 
+// clear a level array inside the cycle.  The library's own kernel; CEDAR_AMD_DEBUG_MEMSET=1 switches back to
+// hipMemsetAsync to reproduce the runtime defect recorded in DESIGN.md section 7 (tools/memset_rootcause.py).
+void clear(real_t *p, size_t n, hipStream_t st)
+{
+	static const bool dbg = getenv("CEDAR_AMD_DEBUG_MEMSET") && atoi(getenv("CEDAR_AMD_DEBUG_MEMSET")) != 0;
+	if (dbg) CEDAR_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(real_t), st));
+	else zero_fill(p, n, st);
+}
+
+// Row-interleaved solve copy of a 27-point level (common.h Op3): read by relax and residual instead of the fourteen
+// Cedar-layout planes.  Measured (profiles/r02_experiment_ilv_layout_ab.log, r02_experiment_ilv_levels.log): 512^3 relax
+// sweep -7 %, V-cycle -3.8 % with the copy on level 0; slower on levels of 256^3 and below => same threshold as the
+// plane-fused pass.  CEDAR_AMD_ILV: 0 never, 1 every 27-point level, n >= 2 levels with at least n rows; default 320.
+// The copy costs 16/14 of the operator again (17.9 GB at 512^3): levels whose copy does not fit beside a 10 % reserve
+// of the card stay on the Cedar layout (1024^3 on one GPU).
+bool ilv_wanted(const Level &L)
+{
+	const char *e = getenv("CEDAR_AMD_ILV");
+	const int mode = e ? atoi(e) : 320;
+	if (mode <= 0 || (L.II - 2 + 1) / 2 > 512) return false;
+	if (!(mode == 1 || L.ny >= mode)) return false;
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+	return ilv_doubles(L.II, L.JJ, L.KK) * sizeof(real_t) + tot / 10 < fr;
+}
+
 void residual(const cedar_amd_solver *s, const Level &L, const real_t *x, const real_t *b, real_t *r, hipStream_t st)
 {
 	if (s->nd == 2) residual2(L.A, b, x, r, L.II, L.JJ, L.nst, st);
+	else if (L.Ailv) residual27_op(op3_ilv(L.Ailv, L.II, L.JJ, L.KK), b, x, r, L.II, L.JJ, L.KK, st);
 	else residual3(L.A, b, x, r, L.II, L.JJ, L.KK, L.nst, st);
 }
 
@@ -133,7 +169,8 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 {
 	for (int it = 0; it < n; it++) {
 		if (s->nd == 3) {
-			relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
+			if (L.Ailv) relax3_gs27_op(op3_ilv(L.Ailv, L.II, L.JJ, L.KK), b, x, L.II, L.JJ, L.KK, updown, st);
+			else relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
 			continue;
 		}
 		const int ipn = s->st.ibc;
@@ -174,7 +211,7 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
 	else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
 	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
-	zero_fill(K.x, K.npts, st); // coarse_x.set(0.0)
+	clear(K.x, K.npts, st); // coarse_x.set(0.0)
 	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
 	else ncycle(s, lvl + 1, K.x, K.b, st);
 	if (s->nd == 2 && s->st.ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, s->st.ibc, st);
@@ -355,6 +392,10 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 			setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
 			galerkin3(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
 			setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, F.KK, st);
+			if (F.nst == 14 && ilv_wanted(F)) {
+				F.Ailv = dalloc_raw(ilv_doubles(F.II, F.JJ, F.KK));
+				ilv_build(F.A, F.SOR0 + F.npts, F.Ailv, F.II, F.JJ, F.KK, st);
+			}
 		}
 	}
 	if (nd == 2 && s->st.ibc) setup_cg2_per(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->st.ibc, s->dinfo, st);
@@ -380,7 +421,7 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 		Level &L = s->lv[l];
 		if (L.ownA) (void)hipFree(L.A);
 		(void)hipFree(L.P); (void)hipFree(L.res); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.yscr);
-		(void)hipFree(L.At); (void)hipFree(L.bt); (void)hipFree(L.xt);
+		(void)hipFree(L.At); (void)hipFree(L.bt); (void)hipFree(L.xt); (void)hipFree(L.Ailv);
 		if (l > 0) { (void)hipFree(L.x); (void)hipFree(L.b); }
 	}
 	(void)hipFree(s->ABD); (void)hipFree(s->bbd); (void)hipFree(s->red); (void)hipFree(s->dinfo);

@@ -1,5 +1,6 @@
-"""Domain-decomposed 3D BoxMG solver: one rank per GPU, halo exchange over
-torch.distributed (backend "nccl" = RCCL over xGMI on the MI355X node).
+"""Domain-decomposed 3D BoxMG solver: one rank per GPU, halo exchange over RCCL / xGMI issued by the
+library itself (cedar_amd/comm.py NativeComm -> cedar_amd_comm_* of include/cedar_amd.h).  No torch in a rank
+process: arrays are `capi.DeviceArray`s, every array operation goes through the backend.
 
 What this replaces in the reference: the MPI flavour's
 Cartesian block decomposition with a one-cell ghost layer exchanged after every
@@ -38,15 +39,16 @@ rank by all-gather and the rest of the cycle runs redundantly on the single-doma
 (one hipGraph replay on the GPU).  This replaces the reference's redistribution solver
 (include/cedar/3d/mpi/redist_solver.h) and, at the last level, its coarsest-grid gather.
 
-The orchestration is backend-agnostic: `GpuBackend` (below) drives the HIP
-kernels through the C ABI on torch CUDA tensors; the test-suite supplies a CPU
-backend so that the same code runs under gloo on CPU (tests/test_dist_cpu.py).
+The orchestration is backend-agnostic.  A backend owns the arrays (opaque here except for `.shape`), the
+kernels and the transport: `GpuBackend` (below) = HIP kernels through the C ABI on device arrays + a `comm`
+object (NativeComm = RCCL; SocketComm = host-staged rehearsal for ranks sharing one GPU); the test-suite supplies
+a CPU backend on the oracle + gloo so that the same code runs on CPU (tests/test_dist_cpu.py).
+Backend interface: zeros(shape), buffer(n), fill_zero(a), box_copy(arr, nplanes, boxes, offs, buf, unpack),
+p2p(sends, recvs) with items (peer, buffer, offset, count), allgather(send, count, recv), allreduce_sum(float),
+side()/wait() for the overlapped exchange, and the kernels.
 """
 import ctypes as C
 import math
-
-import torch
-import torch.distributed as dist
 
 DOWN, UP = 0, 1
 
@@ -120,14 +122,12 @@ def _rng(d, n, recv, has_minus, has_plus):
 
 
 class Halo:
-    """ghost-layer exchange with the (up to 26) neighbouring ranks: pack -> grouped isend/irecv ->
-    unpack.  Packing is one kernel launch through the C ABI when the backend offers `box_copy`
-    (GPU), torch slicing otherwise (CPU tests)."""
+    """ghost-layer exchange with the (up to 26) neighbouring ranks: pack (one launch) -> one grouped
+    send/recv -> unpack (one launch).  Boxes are (i0, j0, k0, ni, nj, nk), 0-based incl. ghost."""
 
-    def __init__(self, topo, n, device, staged, backend=None):
-        self.topo, self.n, self.device, self.staged = topo, n, device, staged
-        self.be = backend if hasattr(backend, "box_copy") else None
-        self.nb = []  # (offset, peer, send box, recv box, size, buffer offset); box = (i0,j0,k0,ni,nj,nk)
+    def __init__(self, topo, n, backend):
+        self.topo, self.n, self.be = topo, n, backend
+        self.nb = []  # (offset, peer, send box, recv box, size, buffer offset)
         off = 0
         hm = [topo.has(d, -1) for d in range(3)]
         hp = [topo.has(d, +1) for d in range(3)]
@@ -147,44 +147,12 @@ class Halo:
         self.groups = {None: list(self.nb),
                        "x": [e for e in self.nb if e[0][0] != 0],
                        "yz": [e for e in self.nb if e[0][0] == 0]}
-        self._tabs = {}
-        if self.be is not None:
-            for g, nb in self.groups.items():
-                if nb:
-                    IntArr, OffArr = C.c_int * (6 * len(nb)), C.c_ulonglong * len(nb)
-                    self._tabs[g] = (IntArr(*[v for e in nb for v in e[2]]), IntArr(*[v for e in nb for v in e[3]]),
-                                     OffArr(*[e[5] for e in nb]))
-        # x-face mini exchange (one box each way), see exchange_x
-        nx, ny, nz = n
-        self._xface = (1, 1, 1, 1, ny, nz)  # template: i0 is filled in per call
+        self._tabs = {g: ([e[2] for e in nb], [e[3] for e in nb], [e[5] for e in nb]) for g, nb in self.groups.items() if nb}
 
-    def _buffers(self, nplanes):
-        if nplanes not in self._buf:
-            mk = lambda: torch.empty(max(self.total, 1) * nplanes, dtype=torch.float64, device=self.device)
-            self._buf[nplanes] = (mk(), mk())
-        return self._buf[nplanes]
-
-    def _p2p(self, sends, recvs):
-        """sends/recvs: lists of (peer, 1-D contiguous tensor)"""
-        if not sends and not recvs:
-            return
-        if self.staged:  # gloo with device tensors (one-GPU rehearsal): stage through host memory
-            hs = [(p, t.cpu()) for p, t in sends]
-            hr = [(p, torch.empty(t.shape, dtype=t.dtype)) for p, t in recvs]
-            ops = [dist.P2POp(dist.isend, t, p) for p, t in hs] + [dist.P2POp(dist.irecv, t, p) for p, t in hr]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            for (_, t), (_, h) in zip(recvs, hr):
-                t.copy_(h)
-            return
-        ops = [dist.P2POp(dist.isend, t, p) for p, t in sends] + [dist.P2POp(dist.irecv, t, p) for p, t in recvs]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-
-    @staticmethod
-    def _view(arr, box):
-        i0, j0, k0, ni, nj, nk = box
-        return arr[..., k0:k0 + nk, j0:j0 + nj, i0:i0 + ni]
+    def _buffers(self, key, count):
+        if key not in self._buf:
+            self._buf[key] = (self.be.buffer(max(count, 1)), self.be.buffer(max(count, 1)))
+        return self._buf[key]
 
     def exchange(self, arr, group=None):
         """fill every ghost cell that has an owner on another rank (group None), or only those owned
@@ -196,22 +164,12 @@ class Halo:
         nplanes = 1
         for v in arr.shape[:-3]:
             nplanes *= int(v)
-        sb, rb = self._buffers(nplanes)
-        if self.be is not None:
-            sboxes, rboxes, offs = self._tabs[group]
-            self.be.box_copy(arr, nplanes, len(nb), sboxes, offs, sb, 0)
-        else:
-            for o, peer, sbox, rbox, size, off in nb:
-                sb[off * nplanes:(off + size) * nplanes].copy_(self._view(arr, sbox).reshape(-1))
-        sends = [(e[1], sb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in nb]
-        recvs = [(e[1], rb[e[5] * nplanes:(e[5] + e[4]) * nplanes]) for e in nb]
-        self._p2p(sends, recvs)
-        if self.be is not None:
-            self.be.box_copy(arr, nplanes, len(nb), rboxes, offs, rb, 1)
-        else:
-            for o, peer, sbox, rbox, size, off in nb:
-                v = self._view(arr, rbox)
-                v.copy_(rb[off * nplanes:(off + size) * nplanes].reshape(v.shape))
+        sb, rb = self._buffers(nplanes, self.total * nplanes)
+        sboxes, rboxes, offs = self._tabs[group]
+        self.be.box_copy(arr, nplanes, sboxes, offs, sb, 0)
+        self.be.p2p([(e[1], sb, e[5] * nplanes, e[4] * nplanes) for e in nb],
+                    [(e[1], rb, e[5] * nplanes, e[4] * nplanes) for e in nb])
+        self.be.box_copy(arr, nplanes, rboxes, offs, rb, 1)
 
     def exchange_x(self, arr, to_minus):
         """x faces only (owned j,k).  to_minus: send the first owned column to the -x neighbour and
@@ -223,45 +181,78 @@ class Halo:
         else:
             send_to, send_col, recv_from, recv_col = +1, nx, -1, 0
         c = t.coord
-        key = ("x", to_minus)
-        if key not in self._buf:
-            mk = lambda: torch.empty(ny * nz, dtype=torch.float64, device=self.device)
-            self._buf[key] = (mk(), mk())
-        sb, rb = self._buf[key]
+        sb, rb = self._buffers(("x", to_minus), ny * nz)
         sends, recvs = [], []
         if t.has(0, send_to):
-            sb.copy_(arr[1:nz + 1, 1:ny + 1, send_col].reshape(-1))
-            sends.append((t.rank_of((c[0] + send_to, c[1], c[2])), sb))
+            self.be.box_copy(arr, 1, [(send_col, 1, 1, 1, ny, nz)], [0], sb, 0)
+            sends.append((t.rank_of((c[0] + send_to, c[1], c[2])), sb, 0, ny * nz))
         if t.has(0, recv_from):
-            recvs.append((t.rank_of((c[0] + recv_from, c[1], c[2])), rb))
-        self._p2p(sends, recvs)
+            recvs.append((t.rank_of((c[0] + recv_from, c[1], c[2])), rb, 0, ny * nz))
+        self.be.p2p(sends, recvs)
         if recvs:
-            arr[1:nz + 1, 1:ny + 1, recv_col].copy_(rb.reshape(nz, ny))
+            self.be.box_copy(arr, 1, [(recv_col, 1, 1, 1, ny, nz)], [0], rb, 1)
         return bool(recvs)
 
 
 # ------------------------------------------------------------------ GPU backend
 class GpuBackend:
-    """HIP kernels through the C ABI (include/cedar_amd.h) on torch CUDA tensors."""
+    """HIP kernels through the C ABI (include/cedar_amd.h) on capi.DeviceArray; transport = `comm`
+    (cedar_amd/comm.py: NativeComm = RCCL issued by the library, SocketComm = one-GPU rehearsal)."""
 
-    def __init__(self, device):
+    def __init__(self, comm, device=0):
         from . import capi
         self.capi, self.lib = capi, capi.lib
-        self.device = device
-        capi.set_device(device.index if device.index is not None else 0)
+        self.comm = comm
+        capi.set_device(device)
+        self._side = None
+        self._tabs = {}
 
     @staticmethod
     def _p(t):
-        return C.c_void_p(t.data_ptr())
+        return C.c_void_p(t.ptr)
 
     @staticmethod
     def _dims(t):
         KK, JJ, II = t.shape[-3:]
         return C.c_uint(II), C.c_uint(JJ), C.c_uint(KK)
 
+    # ---- arrays
     def zeros(self, shape):
-        return torch.zeros(shape, dtype=torch.float64, device=self.device)
+        return self.capi.DeviceArray(shape)
 
+    def buffer(self, n):
+        return self.capi.DeviceArray((int(n),))
+
+    def fill_zero(self, a):
+        a.zero()
+
+    def from_numpy(self, a):
+        return self.capi.DeviceArray.from_numpy(a)
+
+    def to_numpy(self, a):
+        return a.numpy()
+
+    def box_copy(self, arr, nplanes, boxes, offs, buf, unpack):
+        key = (tuple(boxes), tuple(offs))
+        tab = self._tabs.get(key)
+        if tab is None:
+            tab = self._tabs[key] = ((C.c_int * (6 * len(boxes)))(*[v for b in boxes for v in b]),
+                                     (C.c_ulonglong * len(boxes))(*offs))
+        KK, JJ, II = arr.shape[-3:]
+        self.lib.cedar_amd_box_copy(self._p(arr), C.c_uint(II), C.c_uint(JJ), C.c_uint(KK), nplanes, len(boxes),
+                                    tab[0], tab[1], self._p(buf), unpack)
+
+    # ---- transport
+    def p2p(self, sends, recvs):
+        self.comm.p2p(sends, recvs)
+
+    def allgather(self, send, count, recv):
+        self.comm.allgather(send, count, recv)
+
+    def allreduce_sum(self, v):
+        return self.comm.allreduce_sum(v)
+
+    # ---- kernels
     def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0, sides=0):
         """sides: faces of the box with a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z; 0 = all), see cedar_amd.h"""
         self.lib.cedar_amd_relax3_pass_part(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x),
@@ -272,10 +263,10 @@ class GpuBackend:
                                          part | (sides << 4))
 
     class _Side:
-        """`with backend.side() as h:` issues the enclosed work (library launches and collectives) on a
+        """`with backend.side() as h:` issues the enclosed work (library launches and RCCL calls) on a
         side HIP stream ordered after everything already queued on the main stream; `backend.wait(h)`
-        orders the main stream after it.  The main stream is the null stream the library and torch share;
-        torch's side streams are non-blocking, so the two really overlap."""
+        orders the main stream after it.  The main stream is the library's current stream (the null
+        stream by default); the side stream is non-blocking, so the two really overlap."""
 
         def __init__(self, be):
             self.be = be
@@ -283,32 +274,23 @@ class GpuBackend:
         def __enter__(self):
             be = self.be
             if be._side is None:
-                be._side = torch.cuda.Stream(device=be.device)
-            self.main = torch.cuda.current_stream(be.device)
-            ev = torch.cuda.Event()
-            ev.record(self.main)
-            be._side.wait_event(ev)
-            self.ctx = torch.cuda.stream(be._side)
-            self.ctx.__enter__()
-            self.prev = be.lib.cedar_amd_get_stream()
-            be.lib.cedar_amd_set_stream(C.c_void_p(be._side.cuda_stream))
+                from .comm import Stream
+                be._side = Stream()
+            self.main = be.lib.cedar_amd_get_stream()
+            be.lib.cedar_amd_stream_wait(C.c_void_p(be._side.h), C.c_void_p(self.main))
+            be.lib.cedar_amd_set_stream(C.c_void_p(be._side.h))
             return self
 
         def __exit__(self, *exc):
-            be = self.be
-            self.done = torch.cuda.Event()
-            self.done.record(be._side)
-            be.lib.cedar_amd_set_stream(C.c_void_p(self.prev))
-            self.ctx.__exit__(*exc)
+            self.be.lib.cedar_amd_set_stream(C.c_void_p(self.main))
             return False
-
-    _side = None
 
     def side(self):
         return GpuBackend._Side(self)
 
     def wait(self, h):
-        torch.cuda.current_stream(self.device).wait_event(h.done)
+        # everything queued on the side stream so far (= the work of the last `with side()` block)
+        self.lib.cedar_amd_stream_wait(C.c_void_p(self.lib.cedar_amd_get_stream()), C.c_void_p(self._side.h))
 
     def relax_fixup(self, A, b, x, sor, icol, jb, kb):
         self.lib.cedar_amd_relax3_fixup(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), icol, jb, kb)
@@ -349,106 +331,15 @@ class GpuBackend:
                                   num_levels=num_levels, share_operator=True)
 
             def vcycle(h, x, b):
-                capi.lib.cedar_amd_solver_vcycle(h.s.h, x.data_ptr(), b.data_ptr())
+                capi.lib.cedar_amd_solver_vcycle(h.s.h, x.ptr, b.ptr)
         return _H()
-
-    # ---- 2D (cedar_amd/dist2d.py)
-    @staticmethod
-    def _dims2(t):
-        JJ, II = t.shape[-2:]
-        return C.c_uint(II), C.c_uint(JJ)
-
-    def relax_pass2(self, A, b, x, sor, jb, efirst):
-        self.lib.cedar_amd_relax2_pass(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims2(x), jb, int(efirst))
-
-    def relax_fixup2(self, A, b, x, sor, icol, jb):
-        self.lib.cedar_amd_relax2_fixup(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims2(x), icol, jb)
-
-    def relax_colour5(self, A, b, x, sor, jo):
-        self.lib.cedar_amd_relax2_colour5(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims2(x), jo)
-
-    def recip2(self, A, sor):
-        self.lib.BMG2_SymStd_SETUP_recip(self._p(A), self._p(sor), *self._dims2(sor), A.shape[0], 2)
-
-    def residual2(self, A, x, b, r):
-        nst = A.shape[0]
-        II, JJ = self._dims2(x)
-        i = lambda v: C.byref(C.c_int(v))
-        self.lib.BMG2_SymStd_residual(i(0), self._p(A), self._p(b), self._p(x), self._p(r), C.byref(II), C.byref(JJ),
-                                      i(0), i(int(nst == 3)), i(nst), i(0), i(0), i(0), i(0))
-
-    def restrict2(self, r, bc, P):
-        JJ, II = r.shape
-        JJC, IIC = bc.shape
-        self.lib.BMG2_SymStd_restrict(self._p(r), self._p(bc), self._p(P), II, JJ, IIC, JJC, 0)
-
-    def interp_add2(self, x, xc, A, r, P):
-        self.lib.BMG2_SymStd_interp_add(self._p(x), self._p(xc), self._p(r), self._p(A), self._p(P),
-                                        *self._dims2(xc), *self._dims2(x), A.shape[0], 0)
-
-    def interp_phase2(self, A, P, phase, lo):
-        nst = A.shape[0]
-        self.lib.cedar_amd_setup_interp2_phase(self._p(A), self._p(P), *self._dims2(A), *self._dims2(P),
-                                               int(nst == 3), nst, phase, lo[0], lo[1])
-
-    def galerkin2(self, A, Ac, P):
-        nst = A.shape[0]
-        self.lib.BMG2_SymStd_SETUP_ITLI_ex(self._p(A), self._p(Ac), self._p(P), *self._dims2(A), *self._dims2(Ac),
-                                           int(nst == 3), nst, 0)
-
-    def make_serial2(self, gA, relax, pre, post, min_coarse, num_levels):
-        capi = self.capi
-
-        class _H:
-            def __init__(h):
-                h.s = capi.Solver(gA, relax=relax, nrelax_pre=pre, nrelax_post=post, min_coarse=min_coarse,
-                                  num_levels=num_levels, share_operator=True)
-
-            def vcycle(h, x, b):
-                capi.lib.cedar_amd_solver_vcycle(h.s.h, x.data_ptr(), b.data_ptr())
-        return _H()
-
-    def sumsq2(self, r):
-        v = self.capi.lib.cedar_amd_l2norm(r.data_ptr(), r.shape[1], r.shape[0], 1)
-        return v * v
-
-    def affine_lines(self, c, a, div, reverse):
-        """y_i = a_i y_prev + c_i (/ div_i) per row of the (lines, n) tensors; returns y (new tensor)"""
-        y = c.clone()
-        nl, n = y.shape
-        a = a.contiguous()
-        self.lib.cedar_amd_affine_lines(self._p(y), self._p(a), self._p(div.contiguous()) if div is not None else None,
-                                        nl, n, n, int(bool(reverse)))
-        return y
-
-    def lines_rhs2(self, A, b, x, d, lb):
-        """(lines of colour lb, positions): b - (off-line part of A) x, computed by the library"""
-        JJ, II = x.shape
-        nl = ((JJ - 2 - lb + 1) // 2) if d == 0 else ((II - 2 - lb + 1) // 2)
-        n = II - 2 if d == 0 else JJ - 2
-        out = torch.empty((nl, n), dtype=torch.float64, device=self.device)
-        self.lib.cedar_amd_lines_rhs2(self._p(A), self._p(b), self._p(x), self._p(out), *self._dims2(x), A.shape[0], d, lb)
-        return out
-
-    def lines_carry(self, y, p, c):
-        nl, n = y.shape
-        self.lib.cedar_amd_lines_carry(self._p(y), self._p(p), self._p(c.contiguous()), nl, n, n)
-        return y
-
-    def lines_store2(self, xs, x, d, lb):
-        self.lib.cedar_amd_lines_store2(self._p(xs.contiguous()), self._p(x), *self._dims2(x), d, lb)
-
-    def box_copy(self, arr, nplanes, nboxes, boxes, offs, buf, unpack):
-        KK, JJ, II = arr.shape[-3:]
-        self.lib.cedar_amd_box_copy(self._p(arr), C.c_uint(II), C.c_uint(JJ), C.c_uint(KK), nplanes, nboxes,
-                                    boxes, offs, self._p(buf), unpack)
 
     def sumsq(self, r):
-        v = self.capi.lib.cedar_amd_l2norm(r.data_ptr(), r.shape[2], r.shape[1], r.shape[0])
+        v = self.capi.lib.cedar_amd_l2norm(r.ptr, r.shape[2], r.shape[1], r.shape[0])
         return v * v
 
     def sync(self):
-        self.capi.sync()
+        self.lib.cedar_amd_device_sync()
 
 
 # ------------------------------------------------------------------ solver
@@ -464,12 +355,12 @@ class DistSolver3:
         """A_local: (nst, nz+2, ny+2, nx+2) local part of the global operator (ghost layers are
         filled here by exchange; entries coupling to a neighbouring rank must be present)."""
         self.be, self.topo = backend, topo
+        self._gbuf = {}
         self.pre, self.post, self.max_iter, self.tol = nrelax_pre, nrelax_post, max_iter, tol
         self.min_coarse = min_coarse
         self.overlap_min = overlap_min
         # faces of the box with a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z): only rows next to those wait for a halo
         self.sides = (int(topo.has(1, -1)) | int(topo.has(1, +1)) << 1 | int(topo.has(2, -1)) << 2 | int(topo.has(2, +1)) << 3)
-        staged = dist.is_initialized() and dist.get_backend() == "gloo" and A_local.is_cuda
         nst = A_local.shape[0]
         n = tuple(int(s) - 2 for s in A_local.shape[1:][::-1])
         p = topo.p
@@ -497,7 +388,7 @@ class DistSolver3:
                 if p[d] > 1 and l < self.la:
                     assert n[d] % 2 == 0, f"level {l}: local extent {n[d]} in dim {d} must be even"
             shp = (n[2] + 2, n[1] + 2, n[0] + 2)
-            L.halo = Halo(topo, n, A_local.device, staged, backend)
+            L.halo = Halo(topo, n, backend)
             # halo of one row pass in flight under the interior rows of the next (side stream): only
             # where a pass is long enough to hide it and there is a y/z neighbour to talk to
             L.overlap = bool(L.halo.groups["yz"]) and min(n) >= overlap_min and hasattr(backend, "side")
@@ -539,22 +430,29 @@ class DistSolver3:
         self.serial = be.make_serial(self.gA, self.pre, self.post, self.min_coarse, self.nlev_global - self.la)
 
     def _gather_into(self, local, glob):
-        """all-gather the owned block of `local` (..., KK,JJ,II) into the global array"""
-        t = self.topo
+        """all-gather the owned block of `local` (..., KK,JJ,II) into the global array: pack the owned box,
+        one all-gather, unpack every rank's block at its place (one launch each way)"""
+        be, t = self.be, self.topo
         nx, ny, nz = self.cn
-        own = local[..., 1:nz + 1, 1:ny + 1, 1:nx + 1].contiguous()
+        nplanes = 1
+        for v in local.shape[:-3]:
+            nplanes *= int(v)
+        blk = nx * ny * nz
+        key = ("gather", nplanes)
+        if key not in self._gbuf:
+            self._gbuf[key] = (be.buffer(blk * nplanes), be.buffer(blk * nplanes * t.world))
+        sb, rb = self._gbuf[key]
+        be.box_copy(local, nplanes, [(1, 1, 1, nx, ny, nz)], [0], sb, 0)
         if t.world == 1:
-            parts = [own]
+            rb = sb
         else:
-            staged = own.is_cuda and dist.get_backend() == "gloo"
-            src = own.cpu() if staged else own
-            parts = [torch.empty_like(src) for _ in range(t.world)]
-            dist.all_gather(parts, src)
+            be.allgather(sb, blk * nplanes, rb)
         px, py, pz = t.p
-        for r, blk in enumerate(parts):
+        boxes = []
+        for r in range(t.world):
             ci, cj, ck = r % px, (r // px) % py, r // (px * py)
-            glob[..., 1 + ck * nz:1 + (ck + 1) * nz, 1 + cj * ny:1 + (cj + 1) * ny,
-                 1 + ci * nx:1 + (ci + 1) * nx].copy_(blk)
+            boxes.append((1 + ci * nx, 1 + cj * ny, 1 + ck * nz, nx, ny, nz))
+        be.box_copy(glob, nplanes, boxes, [r * blk for r in range(t.world)], rb, 1)
 
     # ---- cycle (vcycle.h:57-115)
     def _smooth(self, L, x, b, updown, n):
@@ -617,13 +515,19 @@ class DistSolver3:
         """levels la.. : gather the right-hand side, one single-domain cycle (or the direct solve when
         la is the coarsest level) from a zero initial guess, keep the own block + ghosts"""
         t = self.topo
+        be = self.be
         self._gather_into(b, self.gb)
-        self.gx.zero_()
+        be.fill_zero(self.gx)
         self.serial.vcycle(self.gx, self.gb)
         nx, ny, nz = self.cn
         ci, cj, ck = t.coord
         # own block plus ghost layer straight from the global solution
-        x.copy_(self.gx[ck * nz:ck * nz + nz + 2, cj * ny:cj * ny + ny + 2, ci * nx:ci * nx + nx + 2])
+        full = (nx + 2) * (ny + 2) * (nz + 2)
+        if "cs" not in self._gbuf:
+            self._gbuf["cs"] = be.buffer(full)
+        tmp = self._gbuf["cs"]
+        be.box_copy(self.gx, 1, [(ci * nx, cj * ny, ck * nz, nx + 2, ny + 2, nz + 2)], [0], tmp, 0)
+        be.box_copy(x, 1, [(0, 0, 0, nx + 2, ny + 2, nz + 2)], [0], tmp, 1)
 
     def _cycle(self, l, x, b):
         be = self.be
@@ -632,7 +536,7 @@ class DistSolver3:
         be.residual(L.A, x, b, L.res)
         L.halo.exchange(L.res)
         be.restrict(L.res, K.b, K.P)
-        K.x.zero_()
+        be.fill_zero(K.x)
         if l + 1 == len(self.levels) - 1:
             self._coarse_solve(K.x, K.b)
         else:
@@ -648,12 +552,10 @@ class DistSolver3:
             self._cycle(0, x, b)
 
     def _norm(self, r):
-        s = torch.tensor([self.be.sumsq(r)], dtype=torch.float64)
+        s = self.be.sumsq(r)
         if self.topo.world > 1:
-            if dist.get_backend() == "nccl":
-                s = s.to(r.device)
-            dist.all_reduce(s)
-        return math.sqrt(float(s.item()))
+            s = self.be.allreduce_sum(s)
+        return math.sqrt(s)
 
     def solve(self, b, x):
         """multilevel::solve (multilevel.h:277-298); returns [||r0||, rel_1, ...]"""

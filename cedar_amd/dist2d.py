@@ -32,7 +32,8 @@ import math
 import torch
 import torch.distributed as dist
 
-from .dist import Halo, Topology
+from ._torch_dist import Halo
+from .dist import Topology
 
 DOWN, UP = 0, 1
 

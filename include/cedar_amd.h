@@ -247,6 +247,41 @@ float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const re
  * returns elapsed milliseconds (HIP events on the library's stream) */
 float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n);
 
+/* ------------------------------------------------------------------ 3. rank-to-rank transport (RCCL over xGMI)
+ * What the reference's MPI flavour does through its MSG library and MPI collectives -- the ghost-layer exchange
+ * after each colour / residual / interp_add (src/3d/ftn/mpi/BMG3_SymStd_relax_GS.f90:102-147,
+ * src/3d/mpi/msg_exchanger.cc:188-197, src/2d/ftn/mpi/mpi_msg.F:425-550), the norm all-reduce
+ * (include/cedar/3d/mpi/grid_func.h:41) and the coarse gather (include/cedar/3d/mpi/redist_solver.h:221-224) --
+ * as RCCL calls issued by the library itself on its current stream (cedar_amd_set_stream).  One communicator per
+ * process / GPU; the 128-byte unique id is made by rank 0 and handed to every rank by the launcher (any channel:
+ * cedar_amd/comm.py uses a TCP socket).  librccl.so.1 is loaded on first use; all buffers are device pointers.
+ * Functions returning int return 0 on success and report through print_error otherwise. */
+#define CEDAR_AMD_COMM_ID_BYTES 128
+typedef struct cedar_amd_comm cedar_amd_comm;
+int cedar_amd_comm_available(void);                      /* 1 if librccl.so.1 could be loaded */
+const char *cedar_amd_comm_why_unavailable(void);
+int cedar_amd_comm_unique_id(void *id128);               /* ncclGetUniqueId */
+cedar_amd_comm *cedar_amd_comm_create(const void *id128, int rank, int world);  /* ncclCommInitRank on the current device */
+void cedar_amd_comm_destroy(cedar_amd_comm *c);
+int cedar_amd_comm_rank(const cedar_amd_comm *c);
+int cedar_amd_comm_size(const cedar_amd_comm *c);
+/* one grouped point-to-point exchange: ncclGroupStart; ncclRecv x nrecv; ncclSend x nsend; ncclGroupEnd (counts in doubles) */
+int cedar_amd_comm_exchange(cedar_amd_comm *c, int nsend, const int *speer, const real_t *const *sbuf, const size_t *scount,
+                            int nrecv, const int *rpeer, real_t *const *rbuf, const size_t *rcount);
+int cedar_amd_comm_allreduce_sum(cedar_amd_comm *c, real_t *buf, size_t n);     /* in place */
+int cedar_amd_comm_allreduce_max(cedar_amd_comm *c, real_t *buf, size_t n);
+int cedar_amd_comm_allgather(cedar_amd_comm *c, const real_t *send, real_t *recv, size_t count); /* recv: world*count */
+int cedar_amd_comm_broadcast(cedar_amd_comm *c, real_t *buf, size_t count, int root);
+/* streams for the overlapped halo exchange: a non-blocking side stream; `waiter` waits for what is queued on `waited` now */
+void *cedar_amd_stream_create(void);
+void cedar_amd_stream_destroy(void *stream);
+void cedar_amd_stream_wait(void *waiter, void *waited);
+void cedar_amd_device_sync(void);
+/* HIP events on the library's current stream: record returns a new event; elapsed waits for e1 */
+void *cedar_amd_event_record(void);
+float cedar_amd_event_elapsed_ms(void *e0, void *e1);
+void cedar_amd_event_destroy(void *event);
+
 const char *cedar_amd_version(void);
 
 #ifdef __cplusplus

@@ -21,6 +21,49 @@ class CpuBackend:
     def zeros(self, shape):
         return torch.zeros(shape, dtype=torch.float64)
 
+    # ---- array / transport interface of cedar_amd.dist (gloo on CPU tensors)
+    def buffer(self, n):
+        return torch.zeros(int(n), dtype=torch.float64)
+
+    def fill_zero(self, a):
+        a.zero_()
+
+    @staticmethod
+    def _view(arr, box):
+        i0, j0, k0, ni, nj, nk = box
+        return arr[..., k0:k0 + nk, j0:j0 + nj, i0:i0 + ni]
+
+    def box_copy(self, arr, nplanes, boxes, offs, buf, unpack):
+        # buffer layout of cedar_amd_box_copy: box b at offs[b]*nplanes, plane-major inside
+        for box, off in zip(boxes, offs):
+            v = self._view(arr, box)
+            size = box[3] * box[4] * box[5]
+            seg = buf[off * nplanes:(off + size) * nplanes]
+            if unpack:
+                v.copy_(seg.reshape(v.shape))
+            else:
+                seg.copy_(v.reshape(-1))
+
+    def p2p(self, sends, recvs):
+        import torch.distributed as dist
+        if not sends and not recvs:
+            return
+        ops = [dist.P2POp(dist.isend, b[o:o + c], p) for p, b, o, c in sends] + \
+              [dist.P2POp(dist.irecv, b[o:o + c], p) for p, b, o, c in recvs]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def allgather(self, send, count, recv):
+        import torch.distributed as dist
+        parts = [recv[r * count:(r + 1) * count] for r in range(dist.get_world_size())]
+        dist.all_gather(parts, send[:count])
+
+    def allreduce_sum(self, v):
+        import torch.distributed as dist
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
+
     def relax_pass(self, A, b, x, sor, jb, kb, efirst, part=0, sides=0):
         # the fused device kernel = the two i-colours of the row class back to back, no exchange between;
         # part 1 / 2 = interior rows / shell rows of the class (cedar_amd_relax3_pass_part)

@@ -1,15 +1,16 @@
-"""GPU multi-rank test runnable on the one-GPU box: 2 ranks share cuda:0, gloo transport (RCCL
-refuses two ranks on one device), HIP kernels through the C ABI.  Same criterion as
-tests/test_dist_cpu.py: the decomposed run reproduces the single-domain history."""
+"""GPU multi-rank tests runnable on the one-GPU box.  No torch in any rank process.
+* 2 / 4 ranks share device 0 and talk through the host-staged rehearsal transport (cedar_amd/comm.py SocketComm: RCCL
+  refuses two ranks on one device); HIP kernels through the C ABI.  Same criterion as tests/test_dist_cpu.py: the
+  decomposed run reproduces the single-domain history (the reference's test/3d/mpi/test_relax.cc:56-59).
+* the RCCL transport itself (NativeComm -> cedar_amd_comm_* -> librccl) with the one rank a one-GPU box allows: a
+  grouped self send/recv, all-reduce, all-gather, and a whole DistSolver3 solve on a 1x1x1 rank grid."""
+import multiprocessing as mp
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -30,12 +31,16 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    import problems as pb
+    from cedar_amd import capi
+    from cedar_amd.comm import SocketComm
+    from cedar_amd.dist import DistSolver3, GpuBackend, Topology
+    assert "torch" not in sys.modules
+    capi.set_device(0)
+    comm = SocketComm(rank, world)
     try:
-        import problems as pb
-        from cedar_amd.dist import DistSolver3, GpuBackend, Topology
-        dev = torch.device("cuda", 0)
-        torch.cuda.set_device(dev)
+        be = GpuBackend(comm, 0)
         topo = Topology(rank, world, pgrid)
         gn = tuple(n[d] * topo.p[d] for d in range(3))
         g = (gn[2] + 2, gn[1] + 2, gn[0] + 2)
@@ -45,16 +50,30 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
         sl = (slice(ck * n[2], ck * n[2] + n[2] + 2), slice(cj * n[1], cj * n[1] + n[1] + 2),
               slice(ci * n[0], ci * n[0] + n[0] + 2))
         m = pb.interior_mask(tuple(s.stop - s.start for s in sl)).astype(np.float64)
-        A = torch.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m).to(dev)
-        b = torch.from_numpy(np.ascontiguousarray(gb[sl]) * m).to(dev)
-        x = torch.zeros_like(b)
-        s = DistSolver3(GpuBackend(dev), topo, A, max_iter=5, overlap_min=overlap_min)
+        A = be.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m)
+        b = be.from_numpy(np.ascontiguousarray(gb[sl]) * m)
+        x = be.zeros(b.shape)
+        s = DistSolver3(be, topo, A, max_iter=5, overlap_min=overlap_min)
         h = s.solve(b, x)
-        np.save(os.path.join(outdir, f"x{rank}.npy"), x.cpu().numpy())
+        np.save(os.path.join(outdir, f"x{rank}.npy"), x.numpy())
         if rank == 0:
             np.save(os.path.join(outdir, "hist.npy"), np.array(h))
     finally:
-        dist.destroy_process_group()
+        comm.close()
+
+
+def _spawn(target, world, args):
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=target, args=(r, world) + args) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(900)
+    bad = [p.exitcode for p in ps if p.exitcode != 0]
+    for p in ps:
+        if p.is_alive():
+            p.kill()
+    assert not bad, f"rank processes failed: exit codes {bad}"
 
 
 # overlap_min = 4: the y/z halo of a row pass travels on a side HIP stream under the interior rows of
@@ -73,7 +92,7 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
 def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, oracle):
     import problems as pb
     world = pgrid[0] * pgrid[1] * pgrid[2]
-    mp.spawn(_worker, args=(world, _free_port(), n, pgrid, str(tmp_path), overlap_min), nprocs=world, join=True)
+    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), overlap_min))
     gn = tuple(n[d] * pgrid[d] for d in range(3))
     g = (gn[2] + 2, gn[1] + 2, gn[0] + 2)
     gso = pb.random_op(g, 14, 77)
@@ -92,3 +111,67 @@ def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, 
         ref = x[ck * n[2]:ck * n[2] + n[2] + 2, cj * n[1]:cj * n[1] + n[1] + 2, ci * n[0]:ci * n[0] + n[0] + 2]
         own = (slice(1, -1),) * 3
         assert np.max(np.abs(xr[own] - ref[own])) <= 1e-12 * np.max(np.abs(x))
+
+
+def _rccl_worker(rank, world, port, outdir):
+    for p in (HERE, ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    import problems as pb
+    from cedar_amd import capi
+    from cedar_amd.comm import NativeComm, Stream
+    from cedar_amd.dist import DistSolver3, GpuBackend, Topology
+    assert "torch" not in sys.modules
+    capi.set_device(0)
+    comm = NativeComm(rank, world)
+    out = {}
+    # grouped self send/recv of two messages, on a side stream of the library
+    a = capi.DeviceArray.from_numpy(np.arange(1000.0))
+    r = capi.DeviceArray((1000,))
+    st = Stream()
+    main = capi.lib.cedar_amd_get_stream()
+    capi.lib.cedar_amd_stream_wait(st.h, main)
+    capi.lib.cedar_amd_set_stream(st.h)
+    comm.p2p([(0, a, 0, 600), (0, a, 600, 400)], [(0, r, 0, 600), (0, r, 600, 400)])
+    capi.lib.cedar_amd_set_stream(main)
+    capi.lib.cedar_amd_stream_wait(main, st.h)
+    capi.lib.cedar_amd_device_sync()
+    out["p2p"] = bool(np.array_equal(r.numpy(), np.arange(1000.0)))
+    out["sum"] = comm.allreduce_sum(3.5)
+    g = capi.DeviceArray((1000,))
+    comm.allgather(a, 1000, g)
+    capi.sync()
+    out["gather"] = bool(np.array_equal(g.numpy(), np.arange(1000.0)))
+    # the whole distributed solver on a 1x1x1 rank grid over RCCL (all-gather of the coarse level, norm all-reduce)
+    n = (24, 20, 16)
+    g3 = (n[2] + 2, n[1] + 2, n[0] + 2)
+    so = pb.random_op(g3, 14, 77)
+    b = pb.uniform(g3, 78, -1, 1) * pb.interior_mask(g3)
+    be = GpuBackend(comm, 0)
+    s = DistSolver3(be, Topology(0, 1), be.from_numpy(so), max_iter=4, agglomerate_below=8)
+    x = be.zeros(b.shape)
+    out["hist"] = [float(v) for v in s.solve(be.from_numpy(b), x)]
+    comm.close()
+    import json
+    json.dump(out, open(os.path.join(outdir, "rccl.json"), "w"))
+
+
+def test_rccl_transport_one_rank(tmp_path, oracle):
+    """ncclCommInitRank / grouped ncclSend+ncclRecv / ncclAllReduce / ncclAllGather through the library's C ABI"""
+    import json
+    import problems as pb
+    _spawn(_rccl_worker, 1, (_free_port(), str(tmp_path)))
+    out = json.load(open(tmp_path / "rccl.json"))
+    assert out["p2p"] and out["gather"] and out["sum"] == 3.5
+    n = (24, 20, 16)
+    g3 = (n[2] + 2, n[1] + 2, n[0] + 2)
+    so = pb.random_op(g3, 14, 77)
+    b = pb.uniform(g3, 78, -1, 1) * pb.interior_mask(g3)
+    ml = oracle.ml_create(so)
+    x = np.zeros_like(b)
+    want = ml.solve(b, x, maxiter=4)
+    ml.close()
+    np.testing.assert_allclose(out["hist"], want, rtol=1e-10, atol=1e-14)

@@ -34,7 +34,8 @@ def _worker(rank, world, port, case, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import problems as pb
-        from cedar_amd.dist import GpuBackend, Topology
+        from cedar_amd._torch_dist import GpuBackend
+        from cedar_amd.dist import Topology
         from cedar_amd.dist2d import DistSolver2
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
