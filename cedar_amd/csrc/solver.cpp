@@ -428,15 +428,29 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 	delete s;
 }
 
-int cedar_amd_solver_nlevels(const cedar_amd_solver *s) { return (int)s->lv.size(); }
+// every entry point below tolerates the NULL that cedar_amd_solver_create returns for unsupported settings:
+// it reports through print_error and does nothing (the reference never aborts either)
+static bool null_handle(const void *s, const char *who)
+{
+	if (s) return false;
+	char msg[160];
+	snprintf(msg, sizeof(msg), "%s: NULL solver handle (cedar_amd_solver_create reported why no solver was created)", who);
+	print_error(msg);
+	return true;
+}
+
+int cedar_amd_solver_nlevels(const cedar_amd_solver *s) { return null_handle(s, "cedar_amd_solver_nlevels") ? 0 : (int)s->lv.size(); }
 
 void cedar_amd_solver_level_dims(const cedar_amd_solver *s, int lvl, len_t *nx, len_t *ny, len_t *nz)
 {
+	*nx = *ny = *nz = 0;
+	if (null_handle(s, "cedar_amd_solver_level_dims") || lvl < 0 || lvl >= (int)s->lv.size()) return;
 	*nx = s->lv[lvl].nx; *ny = s->lv[lvl].ny; *nz = s->lv[lvl].nz;
 }
 
 size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what, real_t *out)
 {
+	if (null_handle(s, "cedar_amd_solver_get") || lvl < 0 || lvl >= (int)s->lv.size()) return 0;
 	const Level &L = s->lv[lvl];
 	const real_t *src = nullptr;
 	size_t n = 0;
@@ -454,6 +468,7 @@ size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what
 
 void cedar_amd_solver_vcycle(cedar_amd_solver *s, real_t *x, const real_t *b)
 {
+	if (null_handle(s, "cedar_amd_solver_vcycle")) return;
 	const Level &L = s->lv[0];
 	Staged sx(x, L.npts, true, true), sb(b, L.npts, true, false);
 	if (sx.staged() || sb.staged()) {
@@ -465,6 +480,7 @@ void cedar_amd_solver_vcycle(cedar_amd_solver *s, real_t *x, const real_t *b)
 
 int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real_t *rel)
 {
+	if (null_handle(s, "cedar_amd_solver_solve")) return 0;
 	Level &L = s->lv[0];
 	Staged sx(x, L.npts, true, true), sb(b, L.npts, true, false);
 	hipStream_t st = current_stream();
@@ -484,6 +500,7 @@ int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real
 
 float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n)
 {
+	if (null_handle(s, "cedar_amd_solver_time_vcycles")) return 0.f;
 	hipStream_t st = current_stream();
 	hipEvent_t e0, e1;
 	CEDAR_HIP_CHECK(hipEventCreate(&e0));
@@ -500,6 +517,7 @@ float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const re
 
 float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n)
 {
+	if (null_handle(s, "cedar_amd_solver_time_relax")) return 0.f;
 	hipStream_t st = current_stream();
 	const Level &L = s->lv[0];
 	hipEvent_t e0, e1;

@@ -31,9 +31,9 @@ int main()
 	auto kman = bmg.get_kernels();
 	relax_stencil sor(nx, ny, nz);
 	grid_func res(nx, ny, nz);
-	kman->setup<kernels::point_relax>(so.data(), 4, sor);
-	kman->run<kernels::point_relax>(so.data(), 4, sol, b, sor, cycle::Dir::DOWN);
-	kman->run<kernels::residual>(so.data(), 4, sol, b, res);
+	kman->setup<kernels::point_relax<stypes>>(so, sor);
+	kman->run<kernels::point_relax<stypes>>(so, sol, b, sor, cycle::Dir::DOWN);
+	kman->run<kernels::residual<stypes>>(so, sol, b, res);
 	log::status << "Levels: " << bmg.nlevels() << std::endl;
 	log::status << "Residual l2 after one extra sweep: " << res.lp_norm<2>() << std::endl;
 	real_t hx = 1.0 / (nx + 1);

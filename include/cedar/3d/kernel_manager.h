@@ -1,0 +1,178 @@
+// The "hip" implementations of the 3D kernels and the registry that holds them
+// (reference include/cedar/3d/{relax,residual,interp,restrict,coarsen,solve_cg}.h, src/3d/{interp,restrict,solve_cg}.cc,
+// src/3d/kernel_manager.cc).  Each class marshals Cedar's types into the extern "C" symbols the reference's
+// binding classes call -- served by libcedar_amd.so.
+#ifndef CEDAR_3D_KERNEL_MANAGER_H
+#define CEDAR_3D_KERNEL_MANAGER_H
+#include <type_traits>
+#include <cedar/kernel_manager.h>
+#include <cedar/kernels/coarsen_op.h>
+#include <cedar/kernels/interp_add.h>
+#include <cedar/kernels/point_relax.h>
+#include <cedar/kernels/residual.h>
+#include <cedar/kernels/restrict.h>
+#include <cedar/kernels/setup_interp.h>
+#include <cedar/kernels/solve_cg.h>
+#include <cedar/3d/types.h>
+extern "C" {
+#include <cedar_amd.h>
+}
+
+namespace cedar { namespace cdr3 {
+enum { BMG_DOWN = 0, BMG_UP = 1, BMG_RELAX_SYM = 1 };
+
+// include/cedar/3d/relax.h:22-100
+class rbgs : public kernels::point_relax<stypes> {
+public:
+	void setup(const stencil_op<seven_pt> & so, relax_stencil & sor) override { this->setup_impl(so, sor); }
+	void setup(const stencil_op<xxvii_pt> & so, relax_stencil & sor) override { this->setup_impl(so, sor); }
+	void run(const stencil_op<seven_pt> & so, grid_func & x, const grid_func & b, const relax_stencil & sor, cycle::Dir cdir) override
+	{ this->run_impl(so, x, b, sor, cdir); }
+	void run(const stencil_op<xxvii_pt> & so, grid_func & x, const grid_func & b, const relax_stencil & sor, cycle::Dir cdir) override
+	{ this->run_impl(so, x, b, sor, cdir); }
+	template <class sten> void setup_impl(const stencil_op<sten> & so, relax_stencil & sor)
+	{
+		auto & sod = const_cast<stencil_op<sten> &>(so);
+		BMG3_SymStd_SETUP_recip(sod.data(), sor.data(), so.len(0), so.len(1), so.len(2), stencil_ndirs<sten>::value, 2);
+	}
+	template <class sten> void run_impl(const stencil_op<sten> & so, grid_func & x, const grid_func & b, const relax_stencil & sor, cycle::Dir cdir)
+	{
+		auto & sod = const_cast<stencil_op<sten> &>(so);
+		auto & bd = const_cast<grid_func &>(b);
+		auto & sord = const_cast<relax_stencil &>(sor);
+		int ibc;
+		BMG_get_bc(params->per_mask(), &ibc);
+		BMG3_SymStd_relax_GS(1, sod.data(), bd.data(), x.data(), sord.data(), so.len(0), so.len(1), so.len(2),
+		                     std::is_same<sten, seven_pt>::value ? 1 : 0, stencil_ndirs<sten>::value, 2, BMG_RELAX_SYM,
+		                     cdir == cycle::Dir::UP ? BMG_UP : BMG_DOWN, ibc);
+	}
+};
+
+// include/cedar/3d/residual.h:18-60
+class residual_f90 : public kernels::residual<stypes> {
+public:
+	void run(const stencil_op<seven_pt> & so, const grid_func & x, const grid_func & b, grid_func & r) override { this->run_impl(so, x, b, r); }
+	void run(const stencil_op<xxvii_pt> & so, const grid_func & x, const grid_func & b, grid_func & r) override { this->run_impl(so, x, b, r); }
+	template <class sten> void run_impl(const stencil_op<sten> & so, const grid_func & x, const grid_func & b, grid_func & r)
+	{
+		auto & sod = const_cast<stencil_op<sten> &>(so);
+		auto & xd = const_cast<grid_func &>(x);
+		auto & bd = const_cast<grid_func &>(b);
+		BMG3_SymStd_residual(1, 1, std::is_same<sten, seven_pt>::value ? 1 : 0, xd.data(), bd.data(), sod.data(), r.data(),
+		                     r.len(0), r.len(1), r.len(2), stencil_ndirs<sten>::value);
+	}
+};
+
+// src/3d/restrict.cc:15-36
+class restrict_f90 : public kernels::restriction<stypes> {
+public:
+	void run(const restrict_op & R, const grid_func & fine, grid_func & coarse) override
+	{
+		auto & P = const_cast<prolong_op &>(R.getP());
+		auto & fined = const_cast<grid_func &>(fine);
+		int ibc;
+		BMG_get_bc(params->per_mask(), &ibc);
+		BMG3_SymStd_restrict(fined.data(), coarse.data(), P.data(), fined.len(0), fined.len(1), fined.len(2),
+		                     coarse.len(0), coarse.len(1), coarse.len(2), ibc);
+	}
+};
+
+// src/3d/interp.cc:15-45 (NB: so, res order of the 3D kernel)
+class interp_f90 : public kernels::interp_add<stypes> {
+public:
+	void run(const prolong_op & P, const grid_func & coarse, const grid_func & residual, grid_func & fine) override
+	{
+		auto & Pd = const_cast<prolong_op &>(P);
+		auto & coarsed = const_cast<grid_func &>(coarse);
+		auto & res = const_cast<grid_func &>(residual);
+		int nstencil = Pd.fine_is_seven ? 4 : 14, ibc;
+		real_t * fop_data = Pd.fine_is_seven ? Pd.fine_op_seven->data() : Pd.fine_op_xxvii->data();
+		BMG_get_bc(params->per_mask(), &ibc);
+		BMG3_SymStd_interp_add(fine.data(), coarsed.data(), fop_data, res.data(), Pd.data(), coarsed.len(0), coarsed.len(1),
+		                       coarsed.len(2), fine.len(0), fine.len(1), fine.len(2), nstencil, ibc);
+	}
+};
+
+// include/cedar/3d/interp.h:32-95 (the yo scratch of the reference is not needed by the library)
+class setup_interp_f90 : public kernels::setup_interp<stypes> {
+public:
+	void run(const stencil_op<seven_pt> & fop, const stencil_op<xxvii_pt> & cop, prolong_op & P) override
+	{
+		auto & fopd = const_cast<stencil_op<seven_pt> &>(fop);
+		P.fine_op_seven = &fopd;
+		P.fine_is_seven = true;
+		call(fopd.data(), cop, P, fop.len(0), fop.len(1), fop.len(2), 1, 4);
+	}
+	void run(const stencil_op<xxvii_pt> & fop, const stencil_op<xxvii_pt> & cop, prolong_op & P) override
+	{
+		auto & fopd = const_cast<stencil_op<xxvii_pt> &>(fop);
+		P.fine_op_xxvii = &fopd;
+		P.fine_is_seven = false;
+		call(fopd.data(), cop, P, fop.len(0), fop.len(1), fop.len(2), 0, 14);
+	}
+private:
+	void call(real_t * fop, const stencil_op<xxvii_pt> & cop, prolong_op & P, len_t iif, len_t jjf, len_t kkf, int ifd, int nstencil)
+	{
+		auto & copd = const_cast<stencil_op<xxvii_pt> &>(cop);
+		int jpn;
+		BMG_get_bc(params->per_mask(), &jpn);
+		BMG3_SymStd_SETUP_interp_OI(fop, copd.data(), P.data(), iif, jjf, kkf, cop.len(0), cop.len(1), cop.len(2), ifd, nstencil,
+		                            BMG_RELAX_SYM, jpn, nullptr);
+	}
+};
+
+// include/cedar/3d/coarsen.h:24-60
+class galerkin : public kernels::coarsen_op<stypes> {
+public:
+	void run(const prolong_op & P, const stencil_op<seven_pt> & fop, stencil_op<xxvii_pt> & cop) override { this->run_impl(P, fop, cop); }
+	void run(const prolong_op & P, const stencil_op<xxvii_pt> & fop, stencil_op<xxvii_pt> & cop) override { this->run_impl(P, fop, cop); }
+	template <class sten> void run_impl(const prolong_op & P, const stencil_op<sten> & fop, stencil_op<xxvii_pt> & cop)
+	{
+		auto & fopd = const_cast<stencil_op<sten> &>(fop);
+		auto & Pd = const_cast<prolong_op &>(P);
+		int ipn;
+		BMG_get_bc(params->per_mask(), &ipn);
+		auto f = std::is_same<sten, seven_pt>::value ? BMG3_SymStd_SETUP_ITLI07_ex : BMG3_SymStd_SETUP_ITLI27_ex;
+		f(fopd.data(), cop.data(), Pd.data(), fop.len(0), fop.len(1), fop.len(2), cop.len(0), cop.len(1), cop.len(2), ipn);
+	}
+};
+
+// include/cedar/3d/solve_cg.h:18-56, src/3d/solve_cg.cc:16-30
+class solve_cg_f90 : public kernels::solve_cg<stypes> {
+public:
+	void setup(const stencil_op<seven_pt> & so, grid_func & ABD) override { this->setup_impl(so, ABD); }
+	void setup(const stencil_op<xxvii_pt> & so, grid_func & ABD) override { this->setup_impl(so, ABD); }
+	template <class sten> void setup_impl(const stencil_op<sten> & so, grid_func & ABD)
+	{
+		auto & sod = const_cast<stencil_op<sten> &>(so);
+		int ibc;
+		BMG_get_bc(params->per_mask(), &ibc);
+		BMG3_SymStd_SETUP_cg_LU(sod.data(), so.len(0), so.len(1), so.len(2), stencil_ndirs<sten>::value, ABD.data(), ABD.len(0),
+		                        ABD.len(1), ibc);
+	}
+	void run(grid_func & x, const grid_func & b, const grid_func & ABD, real_t * bbd) override
+	{
+		auto & bd = const_cast<grid_func &>(b);
+		auto & abd = const_cast<grid_func &>(ABD);
+		int ibc;
+		BMG_get_bc(params->per_mask(), &ibc);
+		BMG3_SymStd_SOLVE_cg(x.data(), bd.data(), x.len(0), x.len(1), x.len(2), abd.data(), bbd, ABD.len(0), ABD.len(1), ibc);
+	}
+};
+
+using kman_ptr = std::shared_ptr<kernel_manager>;
+inline kman_ptr build_kernel_manager(std::shared_ptr<kernel_params> params)
+{
+	auto km = std::make_shared<kernel_manager>(params);
+	km->add<kernels::point_relax<stypes>, rbgs>("hip");
+	km->add<kernels::residual<stypes>, residual_f90>("hip");
+	km->add<kernels::restriction<stypes>, restrict_f90>("hip");
+	km->add<kernels::interp_add<stypes>, interp_f90>("hip");
+	km->add<kernels::setup_interp<stypes>, setup_interp_f90>("hip");
+	km->add<kernels::coarsen_op<stypes>, galerkin>("hip");
+	km->add<kernels::solve_cg<stypes>, solve_cg_f90>("hip");
+	return km;
+}
+inline kman_ptr build_kernel_manager(config & conf) { return build_kernel_manager(build_kernel_params(conf)); }
+}}
+#endif

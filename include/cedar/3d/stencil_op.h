@@ -1,0 +1,6 @@
+// Source compatibility with callers of the reference (include/cedar/3d/stencil_op.h): the 3D data types of this mirror
+// live together in <cedar/3d/types.h>.
+#ifndef CEDAR_3D_FWD_STENCIL_OP_H
+#define CEDAR_3D_FWD_STENCIL_OP_H
+#include <cedar/3d/types.h>
+#endif

@@ -47,11 +47,15 @@ def test_host_side_of_the_cxx_mirror(tmp_path):
 
 
 @pytest.mark.gpu
-def test_registered_hip_kernels_match_the_oracle(tmp_path, oracle):
-    json.dump({}, open(tmp_path / "config.json", "w"))
+def test_registered_hip_kernels_and_user_kernels(tmp_path, oracle):
+    """tests/cxx/hip_kernels.cc: the "hip" bindings with the reference's signatures against the oracle bit for bit; a
+    kernel written against the reference's abstract point_relax and selected with set<T>("user") is run by
+    solver::solve (which leaves the device-resident path for the reference's per-kernel orchestration) and reproduces
+    the resident history; solver.levels hands out the hierarchy; same agreement for the 3D solver."""
+    json.dump({"solver": {"max-iter": 6}}, open(tmp_path / "config.json", "w"))
     exe = tmp_path / "hip_kernels"
     build("hip_kernels.cc", exe)
-    subprocess.run([str(exe), str(tmp_path)], check=True)
+    p = subprocess.run([str(exe), str(tmp_path)], check=True, capture_output=True, text=True)
     nx, ny = 37, 22
     g = (ny + 2, nx + 2)
     so = pb.fe2(nx, ny)
@@ -68,6 +72,27 @@ def test_registered_hip_kernels_match_the_oracle(tmp_path, oracle):
     oracle.residual2(so, b, x, r)
     assert np.array_equal(np.fromfile(tmp_path / "x.bin").reshape(g), x)
     assert np.array_equal(np.fromfile(tmp_path / "r.bin").reshape(g), r)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    assert got["resident_before"] == 1 and got["resident_after"] == 0
+    # 45 x 38 five-point: 5 levels; the user kernel sets up 4 of them and relaxes 3 times per level visit
+    assert got["nlevels"] == 5 and got["user_setup_calls"] == 4
+    cycles = len(got["hist_user"]) - 1
+    assert cycles >= 1 and got["user_run_calls"] == 3 * 4 * cycles
+    assert got["same_level1_operator"] == 1
+    # same kernels in the same order; only the norm differs (device tree sum vs the host's sequential sum)
+    np.testing.assert_allclose(got["hist_user"], got["hist_resident"], rtol=1e-12)
+    assert got["x_diff"] <= 1e-14 * got["x_max"]
+    np.testing.assert_allclose(got["hist3_orchestrated"], got["hist3_resident"], rtol=1e-12)
+    # and the resident history is the oracle's
+    so5 = pb.poisson2(45, 38)
+    bb = np.zeros((40, 47))
+    jj, ii = np.meshgrid(np.arange(1, 39), np.arange(1, 46), indexing="ij")
+    bb[1:-1, 1:-1] = 1e-3 * ((ii * 7 + jj * 3) % 11 - 5)
+    ml = oracle.ml_create(so5)
+    xo = np.zeros_like(bb)
+    want = ml.solve(bb, xo, maxiter=6)
+    ml.close()
+    np.testing.assert_allclose(got["hist_resident"], want, rtol=1e-10, atol=1e-14)
 
 
 @pytest.mark.gpu
