@@ -214,8 +214,17 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "kernels3d.npz"), **k3)
     np.savez_compressed(os.path.join(GOLD, "sweeps.npz"), **cases.sweep_suite(R))
 
-    hist = {}
+    solves(R)
+    main_periodic(R)
+
+
+def solves(R, only=None):
+    """residual histories of full solves; `only`: regenerate just these entries of solves.json"""
+    path = os.path.join(GOLD, "solves.json")
+    hist = json.load(open(path)) if (only and os.path.exists(path)) else {}
     for name, (mk_op, mk_rhs, st) in cases.SOLVES.items():
+        if only and name not in only:
+            continue
         so, b = mk_op(), mk_rhs()
         ml = RefML(R, so, **st)
         x = np.zeros_like(b)
@@ -231,9 +240,8 @@ def main():
             "x_sum": repr(float(np.cumsum(inner.ravel())[-1])),
         }
         print(name, ml.nlev, h[0], h[1:4], flush=True)
-    with open(os.path.join(GOLD, "solves.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(hist, f, indent=1)
-    main_periodic(R)
 
 
 def main_periodic(R):
@@ -264,5 +272,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "periodic":  # regenerate only the periodic fixtures
         os.makedirs(GOLD, exist_ok=True)
         main_periodic(Ref())
+    elif len(sys.argv) > 2 and sys.argv[1] == "solves":  # python gen_golden.py solves NAME [NAME ...]
+        solves(Ref(), only=set(sys.argv[2:]))
     else:
         main()

@@ -182,6 +182,13 @@ SOLVES = {
                         dict(relax="point", nrelax_pre=2, nrelax_post=1)),
     "poisson7_64_v21": (lambda: pb.poisson3(64, 64, 64), lambda: pb.rhs3(64, 64, 64),
                         dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    # mid sizes (SURVEY 8c list): between the small goldens above and the full-size property tests
+    "fe27_129_v21": (lambda: pb.fe3(129, 129, 129), lambda: pb.rhs3(129, 129, 129),
+                     dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "varcoef9_1024_v21": (lambda: pb.varcoef9(1024, 1024), lambda: pb.rhs2(1024, 1024),
+                          dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "aniso9_1024_linexy": (lambda: pb.aniso9(1024, 1024), lambda: pb.rhs2(1024, 1024),
+                           dict(relax="line-xy", nrelax_pre=2, nrelax_post=1)),
     # F-cycles (include/cedar/cycle/fcycle.h), SURVEY section 8f-3
     "varcoef9_200x120_f21": (lambda: pb.varcoef9(200, 120), lambda: pb.rhs2(200, 120),
                              dict(relax="point", nrelax_pre=2, nrelax_post=1, cycle="f")),
@@ -191,7 +198,8 @@ SOLVES = {
 
 # absolute floor (in units of ||r0||) below which residual histories of two
 # correctly-rounded implementations may differ: eps * cond-ish.  Default 1e-14.
-HIST_ATOL = {"aniso9_512_linexy": 1e-12, "stretch5_800x200_linex": 1e-12, "stretch5_200x800_liney": 1e-12}
+HIST_ATOL = {"aniso9_512_linexy": 1e-12, "stretch5_800x200_linex": 1e-12, "stretch5_200x800_liney": 1e-12,
+             "aniso9_1024_linexy": 1e-12}
 
 
 # --------------------------------------------------------------------------

@@ -156,3 +156,29 @@ def test_2d_benchmark_sizes(capi, wl, monkeypatch):
         s0.vcycle(xc, b)
         s0.close()
         assert np.array_equal(xc.numpy(), xa_h)
+
+
+def test_27pt_256_cubed_history_vs_oracle(capi, oracle):
+    """Between the reference goldens (<= 129^3) and the 512^3 property test: the GPU solve of 27-pt gallery::fe at
+    256^3 against the C oracle run on this box's host, iteration for iteration.  Also checks that the operator-level
+    difference of the row-interleaved solve copy (resident solver) is nil: histories with and without it are equal."""
+    import os
+    n = 256
+    so, b = pb.fe3(n, n, n), pb.rhs3(n, n, n)
+    ml = oracle.ml_create(so)
+    xo = np.zeros_like(b)
+    want = ml.solve(b, xo, maxiter=6)
+    ml.close()
+    hs = {}
+    for ilv in ("0", "1"):
+        os.environ["CEDAR_AMD_ILV"] = ilv
+        try:
+            s = capi.Solver(so, max_iter=6)
+            x = np.zeros_like(b)
+            hs[ilv] = s.solve(b, x)
+            s.close()
+        finally:
+            del os.environ["CEDAR_AMD_ILV"]
+    assert np.array_equal(hs["0"], hs["1"])
+    np.testing.assert_allclose(hs["1"], want, rtol=1e-10, atol=1e-14)
+    assert np.max(np.abs(x - xo)) <= 1e-12 * np.max(np.abs(xo))
