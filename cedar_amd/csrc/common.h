@@ -168,7 +168,10 @@ void zero_fill(real_t *p, size_t n, hipStream_t st);
 void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
 void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0);
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0, const real_t *pf = nullptr);
+// scan-ordered copy of the line factors for the resident solver (lines.hip line_pttrs_pf); 0 doubles = not used
+size_t lines_permuted_doubles(int n, int nlines);
+void lines_permute(const real_t *sor, real_t *pf, int n, int ld, int nlines, size_t PS, hipStream_t st);
 // scratch: line-contiguous buffer of ylines_scratch_doubles(II,JJ) doubles in HBM
 size_t ylines_scratch_doubles(int II, int JJ);
 void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *scratch,
@@ -177,7 +180,7 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st);
 void setup_lines_yt(const real_t *so, real_t *sot, int II, int JJ, int nstncl, hipStream_t st);
 void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt, const real_t *sor,
-                    int II, int JJ, int nstncl, int updown, hipStream_t st);
+                    int II, int JJ, int nstncl, int updown, hipStream_t st, const real_t *pf = nullptr);
 // cgsolve.hip
 void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
 void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);

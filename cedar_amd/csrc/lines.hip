@@ -114,6 +114,13 @@ void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st
 constexpr int CH = 8;
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 3); } // LDS index: one pad per 8 -> stride-9 chunks, no bank conflicts
 
+// (p[0], p[1]) with one 16-byte load (8-byte aligned)
+__device__ __forceinline__ void ldpair2(const real_t *__restrict__ p, real_t *out)
+{
+	const d2u v = *reinterpret_cast<const d2u *>(p);
+	out[0] = v.x; out[1] = v.y;
+}
+
 template <int BS>
 __device__ __forceinline__ void affine_scan(real_t a, real_t c, real_t carry, real_t *wa, real_t *wc,
                                             real_t &y_in, real_t &y_last)
@@ -200,6 +207,112 @@ __device__ __forceinline__ void line_pttrs(real_t *y, int n, const real_t *__res
 	}
 }
 
+// The same solve on a scan-ordered copy of the factors (resident solver, lines longer than a wavefront tile).
+// line_pttrs reads e / d where the scan needs them: lane L owns unknowns 8L .. 8L+7 of a tile, so one wave
+// instruction gathers 64 x 8 bytes spread over 4 KB -- 32 cache lines for 512 useful bytes -- and the sweeps of a
+// line wait on eight such gathers.  Measured at 8192^2 (profiles/r02_experiment_line_relax.log): 0.52 of the 1.34 ms
+// of an x sweep is this solve, 0.22 ms of it the gathers alone.  The copy stores, per line and tile of BS*CH unknowns,
+// the forward multipliers a = -e(i-1), the backward multipliers a = -e(i) and the pivots d(i) in the order the lanes
+// consume them: [tile][kind][m/2][lane][m%2], so every load is a coalesced 16-byte-per-lane stream, and the next
+// tile's factors are requested before the current tile is scanned.  Same values, same chunks, same scan =>
+// bit-identical to line_pttrs.
+template <int BS> __host__ __device__ inline size_t pf_tiles(int n) { return (size_t)(n + BS * CH - 1) / (BS * CH); }
+template <int BS> __host__ __device__ inline size_t pf_line_doubles(int n) { return pf_tiles<BS>(n) * 3 * CH * BS; }
+template <int BS> __device__ __forceinline__ size_t pf_off(int t, int kind, int m, int lane)
+{
+	return ((((size_t)t * 3 + kind) * (CH / 2) + (m >> 1)) * BS + lane) * 2 + (m & 1);
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void lines_permute_kernel(const real_t *__restrict__ sor, real_t *__restrict__ pf,
+                                                            int n, int ld, size_t PS)
+{
+	const int l = blockIdx.x;
+	const real_t *d = sor + (size_t)ld * (l + 1) + 1, *e = sor + PS + (size_t)ld * (l + 1) + 2;
+	real_t *out = pf + (size_t)l * pf_line_doubles<BS>(n);
+	const int nt = (int)pf_tiles<BS>(n);
+	for (int t = 0; t < nt; t++)
+		for (int m = 0; m < CH; m++) {
+			const int r = t * BS * CH + (int)threadIdx.x * CH + m, i = n - 1 - r; // forward position r, backward unknown i
+			out[pf_off<BS>(t, 0, m, threadIdx.x)] = (r < n && r > 0) ? -e[r - 1] : 0.0;
+			out[pf_off<BS>(t, 1, m, threadIdx.x)] = (r < n && r > 0) ? -e[i] : 0.0;
+			out[pf_off<BS>(t, 2, m, threadIdx.x)] = r < n ? d[i] : 1.0;
+		}
+}
+
+template <int BS>
+__device__ __forceinline__ void pf_load(const real_t *__restrict__ pfl, int t, int kind, real_t (&v)[CH])
+{
+#pragma unroll
+	for (int mp = 0; mp < CH / 2; mp++) {
+		const d2u w = *reinterpret_cast<const d2u *>(pfl + pf_off<BS>(t, kind, 2 * mp, threadIdx.x));
+		v[2 * mp] = w.x; v[2 * mp + 1] = w.y;
+	}
+}
+
+template <int BS>
+__device__ __forceinline__ void line_pttrs_pf(real_t *y, int n, const real_t *__restrict__ pfl,
+                                              real_t *wa, real_t *wc, real_t *carry_slot)
+{
+	const int nt = (int)pf_tiles<BS>(n);
+	real_t a[CH], an[CH], dn[CH], dd[CH];
+	pf_load<BS>(pfl, 0, 0, a);
+	real_t carry = 0.0;
+	for (int t = 0; t < nt; t++) {
+		if (t + 1 < nt) pf_load<BS>(pfl, t + 1, 0, an); // next tile, or ...
+		else { pf_load<BS>(pfl, 0, 1, an); pf_load<BS>(pfl, 0, 2, dn); } // ... the first backward tile
+		const int i0 = t * BS * CH + (int)threadIdx.x * CH;
+		real_t c[CH];
+#pragma unroll
+		for (int m = 0; m < CH; m++) c[m] = i0 + m < n ? y[lpad(i0 + m)] : 0.0;
+		real_t A = 1.0, Cc = 0.0;
+#pragma unroll
+		for (int m = 0; m < CH; m++) { Cc = a[m] * Cc + c[m]; A = a[m] * A; }
+		real_t v, last;
+		affine_scan<BS>(A, Cc, carry, wa, wc, v, last);
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			v = a[m] * v + c[m];
+			if (i0 + m < n) y[lpad(i0 + m)] = v;
+		}
+		if (threadIdx.x == BS - 1) *carry_slot = last;
+		__syncthreads();
+		carry = *carry_slot;
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < CH; m++) a[m] = an[m];
+	}
+#pragma unroll
+	for (int m = 0; m < CH; m++) dd[m] = dn[m];
+	carry = 0.0;
+	for (int t = 0; t < nt; t++) {
+		if (t + 1 < nt) { pf_load<BS>(pfl, t + 1, 1, an); pf_load<BS>(pfl, t + 1, 2, dn); }
+		const int r0 = t * BS * CH + (int)threadIdx.x * CH;
+		real_t c[CH];
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			const int r = r0 + m;
+			c[m] = r < n ? y[lpad(n - 1 - r)] / dd[m] : 0.0;
+		}
+		real_t A = 1.0, Cc = 0.0;
+#pragma unroll
+		for (int m = 0; m < CH; m++) { Cc = a[m] * Cc + c[m]; A = a[m] * A; }
+		real_t v, last;
+		affine_scan<BS>(A, Cc, carry, wa, wc, v, last);
+#pragma unroll
+		for (int m = 0; m < CH; m++) {
+			v = a[m] * v + c[m];
+			if (r0 + m < n) y[lpad(n - 1 - r0 - m)] = v;
+		}
+		if (threadIdx.x == BS - 1) *carry_slot = last;
+		__syncthreads();
+		carry = *carry_slot;
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < CH; m++) { a[m] = an[m]; dd[m] = dn[m]; }
+	}
+}
+
 // Generic first-order recurrence over line-contiguous data, one workgroup per line:
 //   forward  (reverse = 0): y_i = a_i * y_{i-1} + c_i,  i = 0..n-1,   y_{-1} = 0
 //   backward (reverse = 1): y_i = a_i * y_{i+1} + c_i,  i = n-1..0,   y_n    = 0
@@ -281,10 +394,11 @@ __device__ __forceinline__ real_t line_sherman_morrison(real_t *y, int n, const 
 
 // YT: the arrays are the transposed ones of a y-line sweep (setup_lines_yt): rows are the y lines, and the two
 // cross terms are added in relax_lines_y.f90's order
-template <int BS, bool NINE, bool SM = false, bool YT = false>
+template <int BS, bool NINE, bool SM = false, bool YT = false, bool PERM = false>
 __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                             real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                            int II, int JJ, int jb, int nlines)
+                                                            int II, int JJ, int jb, int nlines, int dbg,
+                                                            const real_t *__restrict__ pf)
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int npad = (II - 2) + ((II - 2) >> 3) + 1;
@@ -294,8 +408,64 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const size_t row = (size_t)(1 + jb + 2 * (int)L) * sj;
 	const int n = II - 2;
-	// right-hand side (relax_lines_x.f90:106-111 / :128-129), reference term order
-	for (int t = threadIdx.x; t < n; t += BS) {
+	// right-hand side (relax_lines_x.f90:106-111 / :128-129), reference term order.
+	// Lines longer than a wavefront tile: every lane forms the right-hand side of RU pairs of unknowns per pass
+	// with 16-byte loads, all 11 x RU loads of a pass requested before the first is used.  With one point per lane
+	// and pass (below) a wave waits out one HBM round trip per 64 unknowns -- 72 % of the wave cycles of this
+	// kernel were such waits (profiles/r02_lines_sq_counters.txt).
+	int tdone = 0;
+	if (dbg & 2) tdone = n; // experiment: no right-hand side (LDS left as is)
+	else if (BS >= 256) {
+		constexpr int RU = 4;
+		const int npair = n >> 1;
+		for (int pb0 = 0; pb0 < npair; pb0 += BS * RU) {
+			real_t f[RU][2], ks[RU][2], ksn[RU][2], ksw[RU][2], knwe[RU][2], knwn[RU][2], kswne[RU][2], qs[RU][4], qn[RU][4];
+#pragma unroll
+			for (int u = 0; u < RU; u++) {
+				const int pr = pb0 + u * BS + (int)threadIdx.x;
+				if (pr < npair) {
+					const size_t x = row + 1 + 2 * (size_t)pr;
+					ldpair2(qf + x, f[u]);
+					ldpair2(so + KS * PS + x, ks[u]);
+					ldpair2(so + KS * PS + x + sj, ksn[u]);
+					ldpair2(q + x - 1 - sj, &qs[u][0]); ldpair2(q + x + 1 - sj, &qs[u][2]);
+					ldpair2(q + x - 1 + sj, &qn[u][0]); ldpair2(q + x + 1 + sj, &qn[u][2]);
+					if (NINE) {
+						ldpair2(so + KSW * PS + x, ksw[u]);
+						ldpair2(so + KNW * PS + x + 1, knwe[u]);
+						ldpair2(so + KNW * PS + x + sj, knwn[u]);
+						ldpair2(so + KSW * PS + x + 1 + sj, kswne[u]);
+					}
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < RU; u++) {
+				const int pr = pb0 + u * BS + (int)threadIdx.x;
+				if (pr < npair) {
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						real_t s = f[u][h];
+						s = s + ks[u][h] * qs[u][1 + h];
+						s = s + ksn[u][h] * qn[u][1 + h];
+						if (NINE) {
+							s = s + ksw[u][h] * qs[u][h];
+							if (YT) {
+								s = s + knwn[u][h] * qn[u][h];
+								s = s + knwe[u][h] * qs[u][2 + h];
+							} else {
+								s = s + knwe[u][h] * qs[u][2 + h];
+								s = s + knwn[u][h] * qn[u][h];
+							}
+							s = s + kswne[u][h] * qn[u][2 + h];
+						}
+						y[lpad(2 * pr + h)] = s;
+					}
+				}
+			}
+		}
+		tdone = npair * 2; // an odd last unknown goes through the scalar loop
+	}
+	for (int t = tdone + threadIdx.x; t < n; t += BS) {
 		const size_t x = row + 1 + t;
 		real_t s = qf[x];
 		s = s + so[KS * PS + x] * q[x - sj];
@@ -314,7 +484,9 @@ __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restr
 		y[lpad(t)] = s;
 	}
 	__syncthreads();
-	line_pttrs<BS>(y, n, sor + row + 1, sor + PS + row + 2, wa, wc, cs);
+	if (dbg & 1) { /* experiment: no solve */ }
+	else if (PERM) line_pttrs_pf<BS>(y, n, pf + (size_t)(jb + 2 * (int)L) * pf_line_doubles<BS>(n), wa, wc, cs);
+	else line_pttrs<BS>(y, n, sor + row + 1, sor + PS + row + 2, wa, wc, cs);
 	for (int t = threadIdx.x; t < n; t += BS) q[row + 1 + t] = y[lpad(t)];
 	if (SM) {
 		real_t y1, yn;
@@ -347,49 +519,82 @@ static bool lds_ok(int n, const char *who)
 	return true;
 }
 
-template <int BS, bool NINE, bool SM, bool YT = false>
-static void launch_x_k(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, int nlines,
-                       hipStream_t st)
+template <int BS, bool NINE, bool SM, bool YT, bool PERM>
+static void launch_x_kp(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, int nlines,
+                        hipStream_t st, const real_t *pf)
 {
 	size_t shm = line_lds_doubles(II - 2) * sizeof(real_t);
-	auto k = relax_lines_x_kernel<BS, NINE, SM, YT>;
+	auto k = relax_lines_x_kernel<BS, NINE, SM, YT, PERM>;
 	if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-	hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines);
+	const char *ed = getenv("CEDAR_AMD_LINE_DBG"); // timing experiments only (1: no solve, 2: no right-hand side)
+	hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines, ed ? atoi(ed) : 0, pf);
+}
+
+// pf != nullptr: the scan-ordered factor copy of this line direction (lines_permute), Dirichlet lines of the 256-lane kernel
+template <int BS, bool NINE, bool SM, bool YT = false>
+static void launch_x_k(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, int nlines,
+                       hipStream_t st, const real_t *pf)
+{
+	if (!SM && pf && BS >= 256) launch_x_kp<BS, NINE, false, YT, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+	else launch_x_kp<BS, NINE, SM, YT, false>(so, qf, q, sor, II, JJ, jb, nlines, st, nullptr);
 }
 
 template <int BS>
 static void launch_x_n(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                       int nstncl, int jb, hipStream_t st, bool sm, bool yt)
+                       int nstncl, int jb, hipStream_t st, bool sm, bool yt, const real_t *pf)
 {
 	int nlines = (JJ - 2 - jb + 1) / 2;
 	if (nlines <= 0) return;
 	if (yt) { // Dirichlet only
-		if (nstncl == 5) launch_x_k<BS, true, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
-		else launch_x_k<BS, false, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
+		if (nstncl == 5) launch_x_k<BS, true, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+		else launch_x_k<BS, false, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
 	} else if (nstncl == 5) {
-		if (sm) launch_x_k<BS, true, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
-		else launch_x_k<BS, true, false>(so, qf, q, sor, II, JJ, jb, nlines, st);
+		if (sm) launch_x_k<BS, true, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+		else launch_x_k<BS, true, false>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
 	} else {
-		if (sm) launch_x_k<BS, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st);
-		else launch_x_k<BS, false, false>(so, qf, q, sor, II, JJ, jb, nlines, st);
+		if (sm) launch_x_k<BS, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+		else launch_x_k<BS, false, false>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
 	}
 }
 
 static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                     int nstncl, int jb, hipStream_t st, bool sm = false, bool yt = false)
+                     int nstncl, int jb, hipStream_t st, bool sm = false, bool yt = false, const real_t *pf = nullptr)
 {
 	switch (line_bs(II - 2)) {
-	case 64: launch_x_n<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt); break;
-	case 512: launch_x_n<512>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt); break;
-	case 1024: launch_x_n<1024>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt); break;
-	default: launch_x_n<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt);
+	case 64: launch_x_n<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf); break;
+	case 512: launch_x_n<512>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf); break;
+	case 1024: launch_x_n<1024>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf); break;
+	default: launch_x_n<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf);
 	}
 }
 
 // ipn: 0 Dirichlet; 1 periodic in y only: ordinary solves, one y wrap after the sweep (relax_lines_x.f90:75-176);
 // 2 / 3 periodic in x (/ and y): cyclic lines, y then x wrap after each colour (:178-300)
+// scan-ordered factor copy for the lines of `sor` (n unknowns per line, line stride ld, nlines lines): 0 doubles when
+// the line kernel would not use it (lines of at most 512 unknowns run on one wavefront)
+size_t lines_permuted_doubles(int n, int nlines)
+{
+	switch (line_bs(n)) {
+	case 256: return pf_line_doubles<256>(n) * (size_t)nlines;
+	case 512: return pf_line_doubles<512>(n) * (size_t)nlines;
+	case 1024: return pf_line_doubles<1024>(n) * (size_t)nlines;
+	default: return 0;
+	}
+}
+
+void lines_permute(const real_t *sor, real_t *pf, int n, int ld, int nlines, size_t PS, hipStream_t st)
+{
+	if (nlines <= 0 || n <= 0) return;
+	switch (line_bs(n)) {
+	case 256: hipLaunchKernelGGL(lines_permute_kernel<256>, dim3(nlines), dim3(256), 0, st, sor, pf, n, ld, PS); break;
+	case 512: hipLaunchKernelGGL(lines_permute_kernel<512>, dim3(nlines), dim3(512), 0, st, sor, pf, n, ld, PS); break;
+	case 1024: hipLaunchKernelGGL(lines_permute_kernel<1024>, dim3(nlines), dim3(1024), 0, st, sor, pf, n, ld, PS); break;
+	default: break;
+	}
+}
+
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn)
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn, const real_t *pf)
 {
 	if (II < 3 || JJ < 3) return;
 	if (!lds_ok(II - 2, "relax_lines_x")) return;
@@ -397,7 +602,7 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	for (int c = 0; c < 2; c++) {
 		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
 		int jb = (updown == BMG_DOWN) ? 1 - c : c;
-		launch_x(so, qf, q, sor, II, JJ, nstncl, jb, st, sm);
+		launch_x(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, false, sm ? nullptr : pf);
 		if (sm) wrap2(q, II, JJ, 1, ipn == 3, 1, st);
 	}
 	if (ipn == 1) wrap2(q, II, JJ, 1, 1, 0, st);
@@ -592,7 +797,7 @@ void setup_lines_yt(const real_t *so, real_t *sot, int II, int JJ, int nstncl, h
 
 // qft = transposed right-hand side (the caller keeps it while qf is unchanged), qt = scratch for the transposed q
 void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt, const real_t *sor,
-                    int II, int JJ, int nstncl, int updown, hipStream_t st)
+                    int II, int JJ, int nstncl, int updown, hipStream_t st, const real_t *pf)
 {
 	if (II < 3 || JJ < 3) return;
 	if (!lds_ok(JJ - 2, "relax_lines_y")) return;
@@ -602,7 +807,7 @@ void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt,
 		const int nlines = (II - 2 - ib + 1) / 2;
 		if (nlines <= 0) continue;
 		// transposed grid: JJ is the fast extent, II the number of rows
-		launch_x(sot, qft, qt, sor, JJ, II, nstncl, ib, st, false, true);
+		launch_x(sot, qft, qt, sor, JJ, II, nstncl, ib, st, false, true, pf);
 	}
 	transpose2(qt, q, JJ, II, st);
 }

@@ -36,6 +36,9 @@ struct Level {
 	// right-hand side, scratch for the transposed x; bt_fresh: bt holds the transpose of this visit's b
 	real_t *At = nullptr, *bt = nullptr, *xt = nullptr;
 	mutable bool bt_fresh = false;
+	// scan-ordered copies of the line factors (lines.hip line_pttrs_pf): PFx of the x-line factors, PFy of the y-line
+	// factors when the y sweeps run on the transposed arrays; nullptr = the kernels read SOR directly
+	real_t *PFx = nullptr, *PFy = nullptr;
 	// 3D 27-point: row-interleaved solve copy of A and 1/diag (common.h Op3) read by relax and residual
 	real_t *Ailv = nullptr;
 };
@@ -162,7 +165,7 @@ void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int 
 		transpose2(b, L.bt, L.II, L.JJ, st);
 		L.bt_fresh = true;
 	}
-	relax_lines_yt(L.At, L.bt, x, L.xt, sor, L.II, L.JJ, L.nst, updown, st);
+	relax_lines_yt(L.At, L.bt, x, L.xt, sor, L.II, L.JJ, L.nst, updown, st, L.PFy);
 }
 
 void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *b, int updown, int n, hipStream_t st)
@@ -180,15 +183,15 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 		}
 		switch (s->st.relaxation) {
 		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
-		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn); break;
+		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx); break;
 		case CEDAR_AMD_RELAX_LINE_Y: lines_y(L, x, b, L.SOR0, updown, ipn, st); break;
 		default:
 			if (updown == BMG_DOWN) {
-				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx);
 				lines_y(L, x, b, L.SOR1, updown, ipn, st);
 			} else {
 				lines_y(L, x, b, L.SOR1, updown, ipn, st);
-				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx);
 			}
 		}
 	}
@@ -387,6 +390,19 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 				setup_lines_y(F.A, F.SOR1, F.II, F.JJ, st, s->st.ibc == 1 || s->st.ibc == 3);
 			}
 			if (F.At) setup_lines_yt(F.A, F.At, F.II, F.JJ, F.nst, st);
+			if (s->st.ibc == 0 && !(getenv("CEDAR_AMD_LINE_PERM") && atoi(getenv("CEDAR_AMD_LINE_PERM")) == 0)) {
+				// scan-ordered factor copies for the long-line kernel (Dirichlet; periodic lines keep the SOR reads)
+				const int rx = s->st.relaxation;
+				if (rx == CEDAR_AMD_RELAX_LINE_X || rx == CEDAR_AMD_RELAX_LINE_XY) {
+					const size_t nd_ = lines_permuted_doubles(F.II - 2, F.JJ - 2);
+					if (nd_) { F.PFx = dalloc_raw(nd_); lines_permute(F.SOR0, F.PFx, F.II - 2, F.II, F.JJ - 2, F.npts, st); }
+				}
+				if (F.At) { // y factors: SOR(JJ,II,2) in SOR0 (line-y) or SOR1 (line-xy)
+					const real_t *sy = rx == CEDAR_AMD_RELAX_LINE_Y ? F.SOR0 : F.SOR1;
+					const size_t nd_ = lines_permuted_doubles(F.JJ - 2, F.II - 2);
+					if (nd_) { F.PFy = dalloc_raw(nd_); lines_permute(sy, F.PFy, F.JJ - 2, F.JJ, F.II - 2, F.npts, st); }
+				}
+			}
 		} else {
 			int ifd = F.nst == 4;
 			setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
@@ -422,6 +438,7 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 		if (L.ownA) (void)hipFree(L.A);
 		(void)hipFree(L.P); (void)hipFree(L.res); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.yscr);
 		(void)hipFree(L.At); (void)hipFree(L.bt); (void)hipFree(L.xt); (void)hipFree(L.Ailv);
+		(void)hipFree(L.PFx); (void)hipFree(L.PFy);
 		if (l > 0) { (void)hipFree(L.x); (void)hipFree(L.b); }
 	}
 	(void)hipFree(s->ABD); (void)hipFree(s->bbd); (void)hipFree(s->red); (void)hipFree(s->dinfo);

@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 import cases
+import problems as pb
 
 pytestmark = pytest.mark.gpu
 
@@ -279,3 +280,21 @@ def test_lds_tiled_galerkin_is_bit_identical_to_the_slot_kernels(K, monkeypatch,
         K.galerkin3(so, soc, ci)
         out.append(soc)
     assert np.any(out[0] != 0) and np.array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("nx,ny,relax", [(4500, 40, "line-xy"), (3000, 36, "line-x"), (44, 2300, "line-y"), (2049, 700, "line-xy")], ids=str)
+def test_line_solve_on_scan_ordered_factors_is_bit_identical(monkeypatch, nx, ny, relax):
+    """the resident solver runs long lines on a scan-ordered copy of the factors (lines.hip line_pttrs_pf): same
+    values, same chunks, same scan => the same bits as the kernels that read SOR directly (CEDAR_AMD_LINE_PERM=0)"""
+    from cedar_amd import capi
+    so, b = pb.aniso9(nx, ny), pb.rhs2(nx, ny)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CEDAR_AMD_LINE_PERM", flag)
+        s = capi.Solver(so, relax=relax, max_iter=3)
+        x = np.zeros_like(b)
+        h = s.solve(b, x)
+        s.close()
+        outs[flag] = (h, x)
+    assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
+    assert outs["1"][0][-1] < 0.5
