@@ -67,6 +67,16 @@ void pool_put(void *p, size_t bytes)
 	g_pool_bytes += bytes;
 }
 
+void launch_check(const char *who)
+{
+	const hipError_t e = hipGetLastError(); // clears it
+	if (e == hipSuccess) return;
+	char buf[256];
+	snprintf(buf, sizeof(buf), "%s: a kernel launch was rejected by the HIP runtime (%s: %s); results are incomplete", who,
+	         hipGetErrorName(e), hipGetErrorString(e));
+	print_error(buf);
+}
+
 static void report(const char *msg)
 {
 	char buf[256];

@@ -424,6 +424,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		char msg[] = "Coarse grid Cholesky decomp failed!";
 		print_error(msg);
 	}
+	launch_check("cedar_amd_solver_create");
 	return s;
 }
 
@@ -493,6 +494,7 @@ void cedar_amd_solver_vcycle(cedar_amd_solver *s, real_t *x, const real_t *b)
 		cycle_launch(s, sx.get(), sb.get(), current_stream());
 	} else
 		cycle_dev(s, sx.get(), sb.get());
+	launch_check("cedar_amd_solver_vcycle");
 }
 
 int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real_t *rel)
@@ -512,6 +514,7 @@ int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real
 		rel[it + 1] = r;
 		if (r < s->st.tol) { it++; break; }
 	}
+	launch_check("cedar_amd_solver_solve");
 	return it;
 }
 

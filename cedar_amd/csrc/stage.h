@@ -17,6 +17,11 @@ hipStream_t current_stream();
 bool is_device_ptr(const void *p);
 void *pool_get(size_t bytes);
 void pool_put(void *p, size_t bytes);
+// A kernel launch that the runtime rejects (grid dimension above 65535 rows, more LDS than requested with
+// hipFuncSetAttribute, ...) does not return an error from hipLaunchKernelGGL: it leaves one for hipGetLastError and
+// the kernel simply does not run.  Every C-ABI entry point ends with this check (the drop-ins through ~Staged, the
+// handle API explicitly), so a rejected launch is reported through print_error instead of leaving stale results.
+void launch_check(const char *who);
 
 class Staged {
 public:
@@ -35,6 +40,7 @@ public:
 	}
 	~Staged()
 	{
+		launch_check("cedar_amd kernel launch");
 		if (!owned_) return;
 		if (out_) {
 			CEDAR_HIP_CHECK(hipMemcpyAsync(host_, dev_, n_ * sizeof(real_t), hipMemcpyDeviceToHost, current_stream()));
