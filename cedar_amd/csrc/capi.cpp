@@ -141,7 +141,9 @@ void *cedar_amd_malloc(size_t bytes)
 }
 void cedar_amd_free(void *p)
 {
-	if (p) CEDAR_HIP_CHECK(hipFree(p));
+	if (!p) return;
+	relax3_release(static_cast<const real_t *>(p)); // an operator registered with cedar_amd_relax3_prepare goes with its copy
+	CEDAR_HIP_CHECK(hipFree(p));
 }
 void cedar_amd_memcpy_h2d(void *dst, const void *src, size_t bytes)
 {
@@ -469,6 +471,17 @@ void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_
 	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
 	relax3_fixup27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, icol, jb, kb, current_stream());
 }
+
+int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk)
+{
+	if (!is_device_ptr(so) || !is_device_ptr(sor)) return 0; // staged host arrays change address from call to call
+	const char *e = getenv("CEDAR_AMD_ILV");
+	const int mode = e ? atoi(e) : 320;
+	if (mode <= 0) return 0;
+	return relax3_prepare(so, sor, (int)ii, (int)jj, (int)kk, mode == 1 ? 0 : mode, current_stream());
+}
+
+void cedar_amd_relax3_release(const real_t *so) { relax3_release(so); }
 
 void cedar_amd_relax3_colour7(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int pts)
 {

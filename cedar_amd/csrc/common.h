@@ -73,6 +73,10 @@ static inline Op3 op3_ilv(const real_t *a, int II, int JJ, int KK)
 	(void)KK;
 	return Op3{a, RS, NS3 * RS, NS3 * RS * (size_t)JJ, a + ILV_SOR * RS, NS3 * RS, NS3 * RS * (size_t)JJ};
 }
+// register / drop a row-interleaved solve copy for an operator outside a resident solver (relax3d.hip); prepare
+// returns 1 when a copy was built (levels with at least min_rows rows that fit the card's free memory)
+int relax3_prepare(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, hipStream_t st);
+void relax3_release(const real_t *so);
 // build the row-interleaved copy from the Cedar-layout operator (14 slots) and 1/diag plane (relax3d.hip)
 void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, int JJ, int KK, hipStream_t st);
 

@@ -19,6 +19,7 @@
 // is compiled with -ffp-contract=off: results are bit-identical to the
 // reference's CPU build.
 #include "common.h"
+#include <map>
 
 namespace cedar_amd {
 
@@ -77,6 +78,45 @@ void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, in
 {
 	hipLaunchKernelGGL(ilv_build_kernel, dim3((unsigned)((size_t)JJ * KK)), dim3(256), 0, st, so, sor_msor, ilv, II, JJ, KK,
 	                   ilv_row_stride(II));
+}
+
+// Solve copies registered for operators that live outside a resident solver (the per-rank arrays of the
+// domain-decomposed solver, cedar_amd/dist.py): the per-piece entry points below look the operator pointer up and read
+// the row-interleaved copy when there is one.  The caller re-registers after it changed the operator.
+struct IlvReg { real_t *ilv; int II, JJ, KK; };
+static std::map<const real_t *, IlvReg> g_ilv;
+
+int relax3_prepare(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, hipStream_t st)
+{
+	relax3_release(so);
+	if (JJ - 2 < min_rows || (II - 2 + 1) / 2 > 512) return 0;
+	size_t fr = 0, tot = 0;
+	const size_t bytes = ilv_doubles(II, JJ, KK) * sizeof(real_t);
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + tot / 10 >= fr) return 0;
+	real_t *p = nullptr;
+	CEDAR_HIP_CHECK(hipMalloc((void **)&p, bytes));
+	ilv_build(so, sor + (size_t)II * JJ * KK, p, II, JJ, KK, st);
+	g_ilv[so] = IlvReg{p, II, JJ, KK};
+	return 1;
+}
+
+void relax3_release(const real_t *so)
+{
+	auto it = g_ilv.find(so);
+	if (it == g_ilv.end()) return;
+	CEDAR_HIP_CHECK(hipDeviceSynchronize());
+	(void)hipFree(it->second.ilv);
+	g_ilv.erase(it);
+}
+
+static Op3 op3_lookup(const real_t *so, const real_t *sor, int II, int JJ, int KK)
+{
+	if (!g_ilv.empty()) {
+		auto it = g_ilv.find(so);
+		if (it != g_ilv.end() && it->second.II == II && it->second.JJ == JJ && it->second.KK == KK)
+			return op3_ilv(it->second.ilv, II, JJ, KK);
+	}
+	return op3_cedar(so, sor, II, JJ, KK);
 }
 
 // ------------------------------------------------------------------ 27-pt
@@ -512,7 +552,7 @@ void residual27_op(const Op3 &A, const real_t *qf, const real_t *q, real_t *res,
 
 void residual27_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st)
 {
-	residual27_op(op3_cedar(so, nullptr, II, JJ, KK), qf, q, res, II, JJ, KK, st);
+	residual27_op(op3_lookup(so, nullptr, II, JJ, KK), qf, q, res, II, JJ, KK, st);
 }
 
 static inline unsigned cap_grid(size_t n, unsigned bs)
@@ -664,7 +704,7 @@ static void launch_part(bool efirst, const Op3 &A, const real_t *qf, real_t *q,
 void relax3_pass27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                    int II, int JJ, int KK, int jb, int kb, int efirst, hipStream_t st, int part_sides)
 {
-	const Op3 A = op3_cedar(so, sor, II, JJ, KK);
+	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
 	// part_sides = part | sides << 4 (include/cedar_amd.h); no side bit set = every face has a neighbour
 	const int part = part_sides & 3, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	const int npairs = (II - 2 + 1) / 2;
@@ -700,7 +740,7 @@ __global__ void relax27_column(const Op3 A, const real_t *__restrict__ qf, real_
 void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                     int II, int JJ, int KK, int icol, int jb, int kb, hipStream_t st)
 {
-	const Op3 A = op3_cedar(so, sor, II, JJ, KK);
+	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
 	int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
 	if (nj <= 0 || nk <= 0) return;
 	hipLaunchKernelGGL(relax27_column, dim3((nj * nk + 127) / 128), dim3(128), 0, st, A, qf, q, II, JJ, KK, icol, jb, kb);
@@ -740,7 +780,7 @@ static void planes_bs(bool up, const Op3 &A, const real_t *qf, real_t *q,
 void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                      int II, int JJ, int KK, int kb, int up, int part_sides, hipStream_t st)
 {
-	const Op3 A = op3_cedar(so, sor, II, JJ, KK);
+	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
 	const int part = part_sides & 3, sides = ((part_sides >> 4) & 15) ? (part_sides >> 4) & 15 : 15;
 	const int nrk = (KK - 2 - kb + 1) / 2;
 	if (II < 3 || JJ < 3 || nrk <= 0) return;
@@ -815,7 +855,7 @@ void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 {
 	if (II < 3 || JJ < 3 || KK < 3) return;
 	if (nstncl == 14) {
-		relax3_gs27_op(op3_cedar(so, sor, II, JJ, KK), qf, q, II, JJ, KK, updown, st);
+		relax3_gs27_op(op3_lookup(so, sor, II, JJ, KK), qf, q, II, JJ, KK, updown, st);
 	} else {
 		// 7-point: UP = colours 0,1; DOWN = 1,0 (:144-153)
 		for (int c = 0; c < 2; c++) {

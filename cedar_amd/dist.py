@@ -300,6 +300,8 @@ class GpuBackend:
 
     def recip(self, A, sor):
         self.lib.BMG3_SymStd_SETUP_recip(self._p(A), self._p(sor), *self._dims(sor), A.shape[0], 2)
+        # cedar_amd_relax3_prepare (row-interleaved solve copy for the per-piece entry points) is not called here: on
+        # the rank-grid paths it measured neutral (512^3 per rank, profiles/r02_dist_orchestration_cost.log)
 
     def residual(self, A, x, b, r):
         nst = A.shape[0]

@@ -159,6 +159,12 @@ void cedar_amd_relax3_pass_part(real_t *so, real_t *qf, real_t *q, real_t *sor, 
  * the -z / +z bits of the face mask of cedar_amd_relax3_pass_part apply (part | sides << 4). */
 void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                              int kb, int up, int part);
+/* Register the 27-point operator `so` (device pointer, with its SETUP_recip output `sor`) with the library: on levels
+ * with at least 320 rows the pieces above and BMG3_SymStd_relax_GS / _residual then read a row-interleaved solve copy
+ *  instead of the fourteen Cedar-layout planes.  Returns 1 if a copy was made.  Call again after
+ * the operator changed; release before freeing it.  The resident solver (section 2) does this by itself. */
+int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk);
+void cedar_amd_relax3_release(const real_t *so);
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb);

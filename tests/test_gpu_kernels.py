@@ -298,3 +298,28 @@ def test_line_solve_on_scan_ordered_factors_is_bit_identical(monkeypatch, nx, ny
         outs[flag] = (h, x)
     assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
     assert outs["1"][0][-1] < 0.5
+
+
+def test_registered_solve_copy_gives_the_same_bits(K, monkeypatch):
+    """cedar_amd_relax3_prepare: relax / residual on the row-interleaved copy of a registered device operator equal the
+    Cedar-layout kernels bit for bit; freeing the operator through the library drops the registration"""
+    import ctypes as C
+    from cedar_amd import capi
+    monkeypatch.setenv("CEDAR_AMD_ILV", "1")
+    g = (11, 20, 37)
+    so_h, b_h, x_h = pb.random_op(g, 14, 5), pb.uniform(g, 6, -1, 1), pb.uniform(g, 7, -1, 1)
+    so, b = capi.DeviceArray.from_numpy(so_h), capi.DeviceArray.from_numpy(b_h)
+    sor = capi.DeviceArray((2,) + g)
+    K.setup_recip3(so, sor)
+    outs = []
+    for prepared in (False, True):
+        if prepared:
+            capi.lib.cedar_amd_relax3_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]
+            assert capi.lib.cedar_amd_relax3_prepare(so.ptr, sor.ptr, g[2], g[1], g[0]) == 1
+        x, r = capi.DeviceArray.from_numpy(x_h), capi.DeviceArray(g)
+        K.relax3(so, b, x, sor, 0)
+        K.relax3(so, b, x, sor, 1)
+        K.residual3(so, b, x, r)
+        outs.append((x.numpy(), r.numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    so.free()  # cedar_amd_free releases the registration with the operator
