@@ -350,13 +350,18 @@ def main():
     solver.time_relax(x, b, 4)
     ms = solver.time_relax(x, b, nsw)
     per_alloc = [ms / (nsw * launches)]
+    setups = [] if t_setup is None else [t_setup]
     if world == 1 and args.allocations > 1:
         # the sweep time depends on where the operator allocation lands in HBM (7-14 % between allocations of one
         # process, profiles/r01_allocation_placement_variance.log): quote the MEDIAN over fresh allocations of the
         # operator + hierarchy, not the luck of the first one
         for _ in range(args.allocations - 1):
             so2, b2 = build_problem(capi, args.workload, n)
+            capi.sync()
+            ts = time.perf_counter()
             s2 = capi.Solver(so2, relax=relax, share_operator=True)
+            capi.sync()
+            setups.append(time.perf_counter() - ts)
             x2 = capi.DeviceArray(b2.shape)
             s2.time_relax(x2, b2, 4)
             per_alloc.append(s2.time_relax(x2, b2, nsw) / (nsw * launches))
@@ -402,7 +407,10 @@ def main():
                         comm.name if comm is not None else
                         ("RCCL (torch.distributed)" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)"))},
             "roofline": roofline,
-            "setup_ms": None if t_setup is None else t_setup * 1e3,  # device-side interp + Galerkin + relax set-up
+            # device-side interp + Galerkin + relax set-up + solve copies: median over the same fresh allocations (the
+            # first solver of a process also pays for loading every kernel's code object and the first large hipMalloc)
+            "setup_ms": None if not setups else sorted(setups)[len(setups) // 2] * 1e3,
+            "setup_ms_per_allocation": [v * 1e3 for v in setups],
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, relax)

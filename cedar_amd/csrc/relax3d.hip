@@ -248,7 +248,7 @@ __device__ __forceinline__ void ldpair_so(const real_t *__restrict__ p, bool two
 //         j+1 / k+1 are read again by the neighbouring task, the own row is not).
 // WI ("what if", experiments only, results wrong): bit 0 = every q row read from the task's own row, bit 1 = the
 // slot-rows of plane k+1 read from plane k, bit 2 = every inter-plane slot read from KPW -- the loads then hit
-// the caches and the timing shows what removing that traffic would be worth.
+// the caches and the timing shows what removing that traffic would be worth.  8 = the k-pair walk of relax27_plane.
 #define WI_SLOT(slot) ((size_t)(((WI & 4) && ((slot) == KB || (slot) >= KBW)) ? KPW : (slot)))
 template <bool NT, bool NTP = NT, bool NTO = NT, int WI = 0>
 __device__ __forceinline__ void load_pair27(const Op3 &A, const real_t *__restrict__ qf,
@@ -472,6 +472,17 @@ __global__ __launch_bounds__(BS) void relax27_plane(const Op3 A, const real_t *_
 			// jbF = 1: g = nF    likewise
 			__syncthreads();
 			relax27_row_task<BS, EFIRST, NT, false, WI>(A, qf, q, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, xch[t & 1]);
+			t++;
+		}
+	}
+	if (WI & 8) {
+		// what-if "k-pair pass" (timing / traffic only, the dependencies between workgroups are ignored): the rows
+		// of this run in the plane below right after the run -- the nine inter-plane slot-rows both planes read are
+		// then at most one run of row tasks apart
+		for (int r = 2 * f0; r < 2 * f1 && r < JJ - 2; r++) {
+			__syncthreads();
+			relax27_row_task<BS, EFIRST, NT, false, (WI & 7)>(A, qf, q, II, sj, sk, (size_t)(1 + r), k - 1, xch[t & 1]);
+			t++;
 		}
 	}
 }
@@ -611,7 +622,7 @@ static void launch_plane(bool efirst, const Op3 &A, const real_t *qf, real_t *q,
 		else hipLaunchKernelGGL((relax27_plane<256, false, true, W>), dim3(grid), dim3(256), 0, st, A, qf, q, II, JJ, KK, jbF, kb, nrk, frun, nrun, kr0);      \
 		break;
 		if (wi) {
-			switch (wi) { WI_CASE(1) WI_CASE(2) WI_CASE(3) WI_CASE(4) WI_CASE(5) default: break; }
+			switch (wi) { WI_CASE(1) WI_CASE(2) WI_CASE(3) WI_CASE(4) WI_CASE(5) WI_CASE(8) default: break; }
 			launch_rows_at<BS>(efirst, A, qf, q, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, kb, nrk, st, kr0);
 			return;
 		}
@@ -820,8 +831,11 @@ void relax3_gs27_op(const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, i
 		const int frun = plane_frun(JJ);
 		if (npairs <= 512 && frun > 0) {
 			// plane-fused: UP planes of parity 0 then 1, in a plane j-parity 0 rows first; DOWN the reverse
+			const char *ew = getenv("CEDAR_AMD_WHATIF");
+			const bool kpair = ew && atoi(ew) == 8 && npairs > 128 && npairs <= 256; // what-if: ONE launch over plane pairs
 			for (int c = 0; c < 2; c++) {
-				const int kb = up ? c : 1 - c, jbF = up ? 0 : 1;
+				const int kb = kpair ? 1 : (up ? c : 1 - c), jbF = up ? 0 : 1;
+				if (kpair && c == 1) break;
 				if (npairs <= 64) launch_plane<64>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
 				else if (npairs <= 128) launch_plane<128>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
 				else if (npairs <= 256) launch_plane<256>(up, A, qf, q, II, JJ, KK, jbF, kb, frun, st);
