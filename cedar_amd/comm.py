@@ -124,7 +124,7 @@ def bootstrap_bytes(payload, rank, world, timeout=120.0, tag=b""):
         for port in _ports():
             try:
                 with socket.create_connection((host, port), timeout=2.0) as s:
-                    s.settimeout(10.0)
+                    s.settimeout(3.0)  # a foreign service on a candidate port does not answer: move on
                     s.sendall(magic)
                     if _recv_exact(s, len(magic)) != magic:
                         continue

@@ -1,0 +1,47 @@
+"""The launcher side of the RCCL transport without a GPU: rank 0 hands the 128-byte unique id to the other ranks over a
+TCP socket next to MASTER_PORT (cedar_amd/comm.py bootstrap_bytes) -- three processes, a port below it already taken
+(as torch.distributed.run's store takes MASTER_PORT itself), late and early joiners."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, delay, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    time.sleep(delay)
+    from cedar_amd.comm import bootstrap_bytes
+    payload = bytes(range(128)) if rank == 0 else None
+    q.put((rank, bootstrap_bytes(payload, rank, world, timeout=60.0)))
+
+
+def test_unique_id_reaches_every_rank():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.listen(1)  # MASTER_PORT itself stays occupied, like under torch.distributed.run
+    blocker = socket.socket()
+    try:
+        blocker.bind(("127.0.0.1", port + 1))  # and so does the first candidate next to it
+        blocker.listen(1)
+    except OSError:
+        blocker = None
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_worker, args=(r, world, port, d, q)) for r, d in ((0, 0.5), (1, 0.0), (2, 1.0))]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(30)
+    s.close()
+    if blocker:
+        blocker.close()
+    assert all(got[r] == bytes(range(128)) for r in range(world))

@@ -2,7 +2,7 @@
 transport that talks to itself (every message of a (px,py,pz) rank grid is packed, copied device-to-device in place of
 the RCCL send/recv, and unpacked -- the numbers in the ghosts are meaningless, the work per V-cycle is that of one
 rank of the grid) against the resident C solver on the same 27-point problem.  Prints host enqueue time and time per
-V-cycle with the GPU drained.   usage: dist_overhead.py n [pxXpyXpz]"""
+V-cycle with the GPU drained.   usage: dist_overhead.py n [pxXpyXpz [overlap_min]]"""
 import ctypes as C
 import json
 import os
@@ -16,6 +16,7 @@ from cedar_amd.dist import DistSolver3, GpuBackend, Topology
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 pg = tuple(int(v) for v in sys.argv[2].split("x")) if len(sys.argv) > 2 else (1, 1, 1)
+overlap_min = int(sys.argv[3]) if len(sys.argv) > 3 else 96  # levels with fewer points per direction exchange in order
 world = pg[0] * pg[1] * pg[2]
 
 
@@ -46,7 +47,7 @@ pp = (C.c_double * 6)(0.0, 0.0, 0.0, float(n), float(n), float(n))
 capi.lib.cedar_amd_gallery(112, A.ptr, b.ptr, n, n, n, pp)
 centre = tuple(min(1, pg[d] - 1) for d in range(3))
 topo = Topology(centre[2] * pg[0] * pg[1] + centre[1] * pg[0] + centre[0], world, pg)
-ds = DistSolver3(be, topo, A)
+ds = DistSolver3(be, topo, A, overlap_min=overlap_min)
 x = be.zeros(g)
 
 
@@ -65,7 +66,7 @@ def run(f, k):
 
 host, total = run(lambda: ds.vcycle(x, b), 5)
 print(json.dumps({"n": n, "solver": "DistSolver3, one rank of %dx%dx%d%s" % (pg + (" (self-talking mock)" if world > 1 else "",)),
-                  "levels_distributed": len(ds.levels), "host_ms_per_vcycle": host, "ms_per_vcycle": total}), flush=True)
+                  "levels_distributed": len(ds.levels), "overlap_min": overlap_min, "host_ms_per_vcycle": host, "ms_per_vcycle": total}), flush=True)
 s = capi.Solver(A, share_operator=True)
 xs = be.zeros(g)
 host, total = run(lambda: capi.lib.cedar_amd_solver_vcycle(s.h, xs.ptr, b.ptr), 5)
