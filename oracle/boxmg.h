@@ -18,7 +18,7 @@
  *     II = nx+2 etc.  Pointers address the first element including ghosts.
  *   - symmetric half stencils with positive off-diagonals
  *     (src/2d/ftn/BMG_stencils_f90.h:29-71).
- *   - Dirichlet ("definite", ibc = 0) boundaries only.
+ *   - Dirichlet ("definite", ibc = 0) boundaries; the periodic codes live in boxmg2_per.c / boxmg3_per.c.
  * Compiled with -ffp-contract=off so that every expression rounds exactly
  * like the (FMA-free, -O2) flang build of the reference.
  */
@@ -111,6 +111,8 @@ void orc3_relax_colour_part(const real_t *so, const real_t *qf, real_t *q, const
                             len_t II, len_t JJ, len_t KK, int pts, int part);
 void orc3_relax_column(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                        len_t II, len_t JJ, len_t KK, int i, int jb, int kb);
+void orc3_relax_row(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    len_t II, len_t JJ, len_t KK, int ifd, int pts, int j, int k);
 void orc3_setup_interp_ex(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
                           len_t IIC, len_t JJC, len_t KKC, int ifd, int phase_mask, int ilo, int jlo, int klo);
 void orc3_residual(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
@@ -128,6 +130,25 @@ int orc3_setup_cg(const real_t *so, len_t II, len_t JJ, len_t KK, int nstncl,
                   real_t *abd, len_t nabd1, len_t nabd2);
 int orc3_solve_cg(real_t *q, const real_t *qf, len_t II, len_t JJ, len_t KK,
                   const real_t *abd, real_t *bbd, len_t nabd1, len_t nabd2);
+
+/* ---- 3D periodic boundary conditions (boxmg3_per.c); ipn as BMG_get_bc.f90 gives it ---- */
+int orc3_per_x(int ipn);
+int orc3_per_y(int ipn);
+int orc3_per_z(int ipn);
+void orc3_wrap(real_t *a, len_t II, len_t JJ, len_t KK, int nplanes, int ipn);
+void orc3_relax_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                       len_t II, len_t JJ, len_t KK, int ifd, int updown, int ipn);
+void orc3_restrict_per(real_t *q, real_t *qc, const real_t *ci, len_t II, len_t JJ, len_t KK,
+                       len_t IIC, len_t JJC, len_t KKC, int ipn);
+void orc3_interp_add_per(real_t *q, const real_t *qc, const real_t *so, real_t *res, const real_t *ci,
+                         len_t IIC, len_t JJC, len_t KKC, len_t IIF, len_t JJF, len_t KKF, int ipn);
+void orc3_setup_interp_per(const real_t *so, real_t *ci, len_t IIF, len_t JJF, len_t KKF,
+                           len_t IIC, len_t JJC, len_t KKC, int ifd, int ipn);
+void orc3_galerkin_per(const real_t *so, real_t *soc, const real_t *ci, len_t IIF, len_t JJF, len_t KKF,
+                       len_t IIC, len_t JJC, len_t KKC, int ifd, int ipn);
+int orc3_setup_cg_per(const real_t *so, len_t II, len_t JJ, len_t KK, int nstncl, real_t *abd, len_t nabd1, int ipn);
+int orc3_solve_cg_per(real_t *q, const real_t *qf, len_t II, len_t JJ, len_t KK,
+                      const real_t *abd, real_t *bbd, len_t nabd1, int ipn);
 
 /* ---- LAPACK subset (lapack_mini.c): reference-LAPACK 3.x algorithms ---- */
 int orc_dpttrf(int n, real_t *d, real_t *e);

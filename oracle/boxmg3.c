@@ -115,6 +115,21 @@ void orc3_relax_colour(const real_t *so, const real_t *qf, real_t *q, const real
 	}
 }
 
+/* the points of colour pts in row (j,k) (the unit between two x-ghost refreshes of the periodic sweep,
+ * src/3d/ftn/BMG3_SymStd_relax_GS.f90:233-269, :307-322) */
+void orc3_relax_row(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                    len_t II, len_t JJ, len_t KK, int ifd, int pts, int j, int k)
+{
+	int I1 = (int)II - 1;
+	if (ifd != 1) {
+		for (int i = 2 + (pts - 1) % 2; i <= I1; i += 2)
+			Q(i, j, k) = OFFDIAG27(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+	} else {
+		for (int i = (j + k + pts) % 2 + 2; i <= I1; i += 2)
+			Q(i, j, k) = OFFDIAG7(i, j, k) * S3(sor, II, JJ, KK, i, j, k, 1);
+	}
+}
+
 /* one 27-pt colour restricted to a part of its rows: part 1 = rows with 3 <= j <= JJ-2 and
  * 3 <= k <= KK-2 (no ghost row among their neighbours), part 2 = the others (the shell), 0 = all.
  * Rows of one colour do not couple, so interior-then-shell equals the plain colour pass; the

@@ -44,7 +44,9 @@ class RefML:
         the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)"""
         self.R, self.relax, self.pre, self.post, self.cycle = R, relax, nrelax_pre, nrelax_post, cycle
         self.ibc = ibc
-        assert ibc == 0 or so.ndim == 3
+        # 3D: only per_z (5) can be driven end to end: the x / y ghost loops of BMG3_SymStd_interp_add.f90:253-272
+        # are not well defined (pyoracle.Ref.interp_add3)
+        assert ibc == 0 or so.ndim == 3 or ibc == 5
         self.nd = nd = so.ndim - 1
         n = [s - 2 for s in so.shape[1:]][::-1]  # nx, ny[, nz]
         ng = 0
@@ -91,8 +93,9 @@ class RefML:
                     R.setup_lines2(F, self.SOR[l][0], "x")
                     R.setup_lines2(F, self.SOR[l][1], "y")
             else:
-                R.setup_interp3(F, Pm)
-                R.galerkin3(F, K, Pm)
+                kw = dict(ibc=ibc) if ibc else {}
+                R.setup_interp3(F, Pm, **kw)
+                R.galerkin3(F, K, Pm, **kw)
                 R.setup_recip3(F, self.SOR[l][0])
         C = self.A[-1]
         cs = [s - 2 for s in C.shape[1:]][::-1]
@@ -102,6 +105,9 @@ class RefML:
         elif nd == 2:
             self.abd = np.zeros((cs[0] * cs[1], cs[0] + 2))
             R.setup_cg2(C, self.abd)
+        elif ibc:
+            self.abd = np.zeros((cs[0] * cs[1] * cs[2], cs[0] * cs[1] * cs[2]))  # 3d/solver.h:118-121
+            R.setup_cg3(C, self.abd, ibc=ibc)
         else:
             self.abd = np.zeros((cs[0] * cs[1] * cs[2], cs[0] * (cs[1] + 1) + 2))
             R.setup_cg3(C, self.abd)
@@ -110,7 +116,7 @@ class RefML:
         R, A, S = self.R, self.A[l], self.SOR[l]
         for _ in range(n):
             if self.nd == 3:
-                R.relax3(A, b, x, S[0], ud)
+                R.relax3(A, b, x, S[0], ud, **(dict(ibc=self.ibc) if self.ibc else {}))
             elif self.ibc and self.relax == "point":
                 R.relax2(A, b, x, S[0], ud, ibc=self.ibc)
             elif self.ibc:
@@ -156,7 +162,7 @@ class RefML:
         if self.nd == 2:
             R.interp_add2(x, cx, self.res[l], self.A[l], Pm, **kw)
         else:
-            R.interp_add3(x, cx, self.A[l], self.res[l], Pm)
+            R.interp_add3(x, cx, self.A[l], self.res[l], Pm, **kw)
         self._smooth(l, x, b, UP, self.post)
 
     def _fmg(self, l, x, b):
@@ -216,6 +222,7 @@ def main():
 
     solves(R)
     main_periodic(R)
+    main_periodic3(R)
 
 
 def solves(R, only=None):
@@ -241,6 +248,33 @@ def solves(R, only=None):
         }
         print(name, ml.nlev, h[0], h[1:4], flush=True)
     with open(path, "w") as f:
+        json.dump(hist, f, indent=1)
+
+
+def main_periodic3(R):
+    """3D periodic boundary conditions: outputs of the reference kernels that are well defined for the boundary
+    code (cases.kernel_suite_per3), dense coarse solves, and per_z residual histories"""
+    kp = {}
+    for c in cases.CASES_PER3:
+        for k, v in cases.kernel_suite_per3(R, c, reference=True).items():
+            kp[f"{c[0]}/{k}"] = v
+    for c in cases.CG_PER3:
+        for k, v in cases.coarse_solve_per3(R, c).items():
+            kp[f"{c[0]}/{k}"] = v
+    np.savez_compressed(os.path.join(GOLD, "periodic3d.npz"), **kp)
+    hist = {}
+    for name, (mk_op, mk_rhs, st) in cases.SOLVES_PER3.items():
+        if st["ibc"] != 5:
+            continue
+        so, b = mk_op(), mk_rhs()
+        ml = RefML(R, so, **st)
+        x = np.zeros_like(b)
+        h = ml.solve(b, x, maxiter=10, tol=1e-8)
+        inner = x[1:-1, 1:-1, 1:-1]
+        hist[name] = {"settings": st, "nlevels": ml.nlev, "res0_l2": repr(h[0]), "rel_l2": [repr(v) for v in h[1:]],
+                      "x_l2": repr(seq_l2(x)), "x_sum": repr(float(np.cumsum(inner.ravel())[-1]))}
+        print(name, ml.nlev, h[0], h[1:4], flush=True)
+    with open(os.path.join(GOLD, "solves_periodic3d.json"), "w") as f:
         json.dump(hist, f, indent=1)
 
 
@@ -272,6 +306,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "periodic":  # regenerate only the periodic fixtures
         os.makedirs(GOLD, exist_ok=True)
         main_periodic(Ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "periodic3":
+        main_periodic3(Ref())
     elif len(sys.argv) > 2 and sys.argv[1] == "solves":  # python gen_golden.py solves NAME [NAME ...]
         solves(Ref(), only=set(sys.argv[2:]))
     else:

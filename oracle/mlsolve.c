@@ -25,7 +25,8 @@ typedef struct {
 
 struct orc_ml {
 	int nd, nlev, relax, nrelax_pre, nrelax_post, cycle;
-	int ibc;              /* 0 Dirichlet; 2D only: 1 per_y, 2 per_x, 3 per_xy (BMG_get_bc.f90:13-16) */
+	int ibc;              /* 0 Dirichlet; 1 per_y, 2 per_x, 3 per_xy; 3D also 5 per_z, 6 per_xz, 7 per_yz, 8 per_xyz
+	                       * (BMG_get_bc.f90:13-20) */
 	orc_level *lv;
 	real_t *ABD, *bbd;
 	real_t *work;         /* line-relaxation scratch B (2*(II+JJ) of level 0), separate as in the reference */
@@ -78,13 +79,14 @@ orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const 
 	return orc_ml_create_bc(nd, nx, ny, nz, nstencil, so, relax, nrelax_pre, nrelax_post, min_coarse, num_levels, 0);
 }
 
-/* ibc != 0: the kernels' periodic branches (2D, point relaxation); the coarsest operator becomes a
- * dense matrix, ABD(nxc*nyc, nxc*nyc) (include/cedar/2d/solver.h:110-114) */
+/* ibc != 0: the kernels' periodic branches; the coarsest operator becomes a dense matrix,
+ * ABD(nxc*nyc, nxc*nyc) (include/cedar/2d/solver.h:110-114) or ABD(nxc*nyc*nzc, nxc*nyc*nzc)
+ * (include/cedar/3d/solver.h:118-121).  3D: point relaxation, V-cycle. */
 orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
                          int relax, int nrelax_pre, int nrelax_post, int min_coarse,
                          int num_levels, int ibc)
 {
-	if (ibc != 0 && nd != 2) return NULL;
+	if (ibc != 0 && nd == 3 && !(ibc == 1 || ibc == 2 || ibc == 3 || (ibc >= 5 && ibc <= 8))) return NULL;
 	orc_ml *ml = (orc_ml *)calloc(1, sizeof(orc_ml));
 	ml->ibc = ibc;
 	ml->nd = nd; ml->relax = relax;
@@ -106,7 +108,7 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
 	}
 	orc_level *C = &ml->lv[nlev - 1];
 	if (nd == 2) { ml->nabd1 = ibc ? C->nx * C->ny : C->nx + 2; ml->nabd2 = C->nx * C->ny; }
-	else { ml->nabd1 = C->nx * (C->ny + 1) + 2; ml->nabd2 = C->nx * C->ny * C->nz; }
+	else { ml->nabd1 = ibc ? C->nx * C->ny * C->nz : C->nx * (C->ny + 1) + 2; ml->nabd2 = C->nx * C->ny * C->nz; }
 	ml->ABD = zalloc((size_t)ml->nabd1 * ml->nabd2);
 	ml->bbd = zalloc(ml->nabd2);
 	ml->work = zalloc(2 * ((size_t)ml->lv[0].II + ml->lv[0].JJ) + 8);
@@ -137,6 +139,10 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
 				orc2_setup_lines_x(F->A, F->SOR0, F->II, F->JJ);
 				orc2_setup_lines_y(F->A, F->SOR1, F->II, F->JJ);
 			}
+		} else if (ibc) {
+			orc3_setup_interp_per(F->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd, ibc);
+			orc3_galerkin_per(F->A, K->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd, ibc);
+			orc3_setup_recip(F->A, F->SOR0, F->II, F->JJ, F->KK);
 		} else {
 			orc3_setup_interp(F->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd);
 			orc3_galerkin(F->A, K->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd);
@@ -146,6 +152,7 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
 	/* setup_cg_solve (multilevel.h:95-103) */
 	if (nd == 2 && ibc) orc2_setup_cg_per(C->A, C->II, C->JJ, C->nst, ml->ABD, ml->nabd1, ibc);
 	else if (nd == 2) orc2_setup_cg(C->A, C->II, C->JJ, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
+	else if (ibc) orc3_setup_cg_per(C->A, C->II, C->JJ, C->KK, C->nst, ml->ABD, ml->nabd1, ibc);
 	else orc3_setup_cg(C->A, C->II, C->JJ, C->KK, C->nst, ml->ABD, ml->nabd1, ml->nabd2);
 	return ml;
 }
@@ -190,6 +197,10 @@ static void residual(const orc_ml *ml, const orc_level *L, const real_t *x, cons
 static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, int updown, int n)
 {
 	for (int it = 0; it < n; it++) {
+		if (ml->nd == 3 && ml->ibc) {
+			orc3_relax_gs_per(L->A, b, x, L->SOR0, L->II, L->JJ, L->KK, L->nst == 4, updown, ml->ibc);
+			continue;
+		}
 		if (ml->nd == 3) {
 			orc3_relax_gs(L->A, b, x, L->SOR0, L->II, L->JJ, L->KK, L->nst == 4, updown);
 			continue;
@@ -232,6 +243,7 @@ static void coarse_solve(orc_ml *ml, real_t *x, const real_t *b)
 	orc_level *C = &ml->lv[ml->nlev - 1];
 	if (ml->nd == 2 && ml->ibc) orc2_solve_cg_per(x, b, C->II, C->JJ, ml->ABD, ml->bbd, ml->nabd1, ml->ibc);
 	else if (ml->nd == 2) orc2_solve_cg(x, b, C->II, C->JJ, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
+	else if (ml->ibc) orc3_solve_cg_per(x, b, C->II, C->JJ, C->KK, ml->ABD, ml->bbd, ml->nabd1, ml->ibc);
 	else orc3_solve_cg(x, b, C->II, C->JJ, C->KK, ml->ABD, ml->bbd, ml->nabd1, ml->nabd2);
 }
 
@@ -243,12 +255,14 @@ static void ncycle(orc_ml *ml, int lvl, real_t *x, const real_t *b)
 	residual(ml, L, x, b, L->res);
 	if (ml->nd == 2 && ml->ibc) orc2_restrict_per(L->res, K->b, K->P, L->II, L->JJ, K->II, K->JJ, ml->ibc);
 	else if (ml->nd == 2) orc2_restrict(L->res, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
+	else if (ml->ibc) orc3_restrict_per(L->res, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK, ml->ibc);
 	else orc3_restrict(L->res, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK);
 	memset(K->x, 0, K->npts * sizeof(real_t)); /* coarse_x.set(0.0) */
 	if (lvl + 1 == ml->nlev - 1) coarse_solve(ml, K->x, K->b);
 	else ncycle(ml, lvl + 1, K->x, K->b);
 	if (ml->nd == 2 && ml->ibc) orc2_interp_add_per(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ, ml->ibc);
 	else if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
+	else if (ml->ibc) orc3_interp_add_per(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK, ml->ibc);
 	else orc3_interp_add(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK);
 	smooth(ml, L, x, b, BMG_UP, ml->nrelax_post);
 }

@@ -158,9 +158,17 @@ class Oracle:
         _, KK, JJ, II = so.shape
         self.L.orc3_setup_recip(_p(so), _p(sor), u(II), u(JJ), u(KK))
 
-    def relax3(self, so, qf, q, sor, updown):
+    def relax3(self, so, qf, q, sor, updown, ibc=0):
         nst, KK, JJ, II = so.shape
-        self.L.orc3_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), updown)
+        if ibc:
+            self.L.orc3_relax_gs_per(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), updown, ibc)
+        else:
+            self.L.orc3_relax_gs(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), updown)
+
+    def wrap3(self, a, ibc):
+        """periodic ghost refresh of one array or a stack of arrays (y, x, z)"""
+        KK, JJ, II = a.shape[-3:]
+        self.L.orc3_wrap(_p(a), u(II), u(JJ), u(KK), int(a.size // (II * JJ * KK)), ibc)
 
     def relax_colour3(self, so, qf, q, sor, pts):
         nst, KK, JJ, II = so.shape
@@ -185,36 +193,54 @@ class Oracle:
         nst, KK, JJ, II = so.shape
         self.L.orc3_residual(_p(so), _p(qf), _p(q), _p(res), u(II), u(JJ), u(KK), int(nst == 4))
 
-    def restrict3(self, q, qc, ci):
+    def restrict3(self, q, qc, ci, ibc=0):
         KK, JJ, II = q.shape
         KKC, JJC, IIC = qc.shape
-        self.L.orc3_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC))
+        if ibc:
+            self.L.orc3_restrict_per(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), ibc)
+        else:
+            self.L.orc3_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC))
 
-    def interp_add3(self, q, qc, so, res, ci):
+    def interp_add3(self, q, qc, so, res, ci, ibc=0):
         KK, JJ, II = q.shape
         KKC, JJC, IIC = qc.shape
-        self.L.orc3_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK))
+        if ibc:
+            self.L.orc3_interp_add_per(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK), ibc)
+        else:
+            self.L.orc3_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK))
 
-    def setup_interp3(self, so, ci):
+    def setup_interp3(self, so, ci, ibc=0):
         nst, KK, JJ, II = so.shape
         _, KKC, JJC, IIC = ci.shape
-        self.L.orc3_setup_interp(_p(so), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4))
+        if ibc:
+            self.L.orc3_setup_interp_per(_p(so), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4), ibc)
+        else:
+            self.L.orc3_setup_interp(_p(so), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4))
 
-    def galerkin3(self, so, soc, ci):
+    def galerkin3(self, so, soc, ci, ibc=0):
         nst, KK, JJ, II = so.shape
         _, KKC, JJC, IIC = ci.shape
-        self.L.orc3_galerkin(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4))
+        if ibc:
+            self.L.orc3_galerkin_per(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4), ibc)
+        else:
+            self.L.orc3_galerkin(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), int(nst == 4))
 
-    def setup_cg3(self, so, abd):
+    def setup_cg3(self, so, abd, ibc=0):
+        """abd: (n, nx*(ny+1)+2) band storage, or (n, n) dense for a periodic ibc (3d/solver.h:118-121)"""
         nst, KK, JJ, II = so.shape
         n2, n1 = abd.shape
+        if ibc:
+            return self.L.orc3_setup_cg_per(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), ibc)
         return self.L.orc3_setup_cg(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2))
 
-    def solve_cg3(self, q, qf, abd):
+    def solve_cg3(self, q, qf, abd, ibc=0):
         KK, JJ, II = q.shape
         n2, n1 = abd.shape
         bbd = np.zeros(n2)
-        self.L.orc3_solve_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2))
+        if ibc:
+            self.L.orc3_solve_cg_per(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), ibc)
+        else:
+            self.L.orc3_solve_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2))
 
     def l2(self, v):
         if v.ndim == 2:
@@ -234,7 +260,7 @@ class Oracle:
         h = self.L.orc_ml_create_bc(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
                                     nrelax_pre, nrelax_post, min_coarse, num_levels, ibc)
         if not h:
-            raise ValueError("periodic boundary conditions: 2D only")
+            raise ValueError("unknown boundary code %r" % (ibc,))
         m = MLHandle(self, h, nd)
         if cycle == "f":
             self.L.orc_ml_set_cycle(m.h, 1)
@@ -350,45 +376,48 @@ class Ref:
         nst, KK, JJ, II = so.shape
         self.L.BMG3_SymStd_SETUP_recip(_p(so), _p(sor), u(II), u(JJ), u(KK), nst, 2)
 
-    def relax3(self, so, qf, q, sor, updown):
+    def relax3(self, so, qf, q, sor, updown, ibc=0):
         nst, KK, JJ, II = so.shape
-        self.L.BMG3_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), nst, 2, 1, updown, 0)
+        self.L.BMG3_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), nst, 2, 1, updown, ibc)
 
     def residual3(self, so, qf, q, res):
         nst, KK, JJ, II = so.shape
         self.L.BMG3_SymStd_residual(1, 1, int(nst == 4), _p(q), _p(qf), _p(so), _p(res), u(II), u(JJ), u(KK), nst)
 
-    def restrict3(self, q, qc, ci):
+    def restrict3(self, q, qc, ci, ibc=0):
         KK, JJ, II = q.shape
         KKC, JJC, IIC = qc.shape
-        self.L.BMG3_SymStd_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), 0)
+        self.L.BMG3_SymStd_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), ibc)
 
-    def interp_add3(self, q, qc, so, res, ci):
+    def interp_add3(self, q, qc, so, res, ci, ibc=0):
+        """ibc: only 0 and 5 (per_z) are defined by the source: the x / y ghost loops of the routine
+        (BMG3_SymStd_interp_add.f90:253-272) run over stale loop indices"""
+        assert ibc in (0, 5)
         KK, JJ, II = q.shape
         KKC, JJC, IIC = qc.shape
-        self.L.BMG3_SymStd_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK), so.shape[0], 0)
+        self.L.BMG3_SymStd_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK), so.shape[0], ibc)
 
-    def setup_interp3(self, so, ci):
+    def setup_interp3(self, so, ci, ibc=0):
         nst, KK, JJ, II = so.shape
         _, KKC, JJC, IIC = ci.shape
         soc = np.zeros((14, KKC, JJC, IIC))
         yo = np.zeros((14, 2, JJ, II))
         self.L.BMG3_SymStd_SETUP_interp_OI(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC),
-                                           int(nst == 4), nst, 1, 0, _p(yo))
+                                           int(nst == 4), nst, 1, ibc, _p(yo))
 
-    def galerkin3(self, so, soc, ci):
+    def galerkin3(self, so, soc, ci, ibc=0):
         nst, KK, JJ, II = so.shape
         _, KKC, JJC, IIC = ci.shape
         f = self.L.BMG3_SymStd_SETUP_ITLI07_ex if nst == 4 else self.L.BMG3_SymStd_SETUP_ITLI27_ex
-        f(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), 0)
+        f(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), ibc)
 
-    def setup_cg3(self, so, abd):
+    def setup_cg3(self, so, abd, ibc=0):
         nst, KK, JJ, II = so.shape
         n2, n1 = abd.shape
-        self.L.BMG3_SymStd_SETUP_cg_LU(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2), 0)
+        self.L.BMG3_SymStd_SETUP_cg_LU(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2), ibc)
 
-    def solve_cg3(self, q, qf, abd):
+    def solve_cg3(self, q, qf, abd, ibc=0):
         KK, JJ, II = q.shape
         n2, n1 = abd.shape
         bbd = np.zeros(n2)
-        self.L.BMG3_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2), 0)
+        self.L.BMG3_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2), ibc)

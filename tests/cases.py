@@ -300,3 +300,91 @@ SOLVES_PER = {
                                  lambda: pb.periodic_rhs2(100, 75, (True, False)),
                                  dict(relax="line-xy", nrelax_pre=2, nrelax_post=1, ibc=2)),
 }
+
+
+# --------------------------------------------------------------------------
+# 3D periodic boundary conditions.  Even extents in the periodic directions, ny <= nz (the
+# reference's periodic interpolation set-up mixes up the y and z extents otherwise, oracle/boxmg3_per.c).
+# --------------------------------------------------------------------------
+CASES_PER3 = [
+    # (name, nx, ny, nz, nst, ibc)
+    ("q8x10x12_27_x", 8, 10, 12, 14, 2), ("q8x10x12_27_y", 8, 10, 12, 14, 1), ("q8x10x12_27_z", 8, 10, 12, 14, 5),
+    ("q6x4x8_27_xy", 6, 4, 8, 14, 3), ("q12x6x10_27_xz", 12, 6, 10, 14, 6), ("q8x10x12_27_yz", 8, 10, 12, 14, 7),
+    ("q6x8x8_27_xyz", 6, 8, 8, 14, 8), ("q8x10x12_7_x", 8, 10, 12, 4, 2), ("q6x4x8_7_z", 6, 4, 8, 4, 5),
+    ("q4x4x4_7_xyz", 4, 4, 4, 4, 8), ("q8x9x11_27_x", 8, 9, 11, 14, 2), ("q7x8x9_7_y", 7, 8, 9, 4, 1),
+    ("q9x7x10_27_z", 9, 7, 10, 14, 5), ("q16x16x16_27_xyz", 16, 16, 16, 14, 8),
+]
+
+
+def kernel_suite_per3(impl, case, reference=False):
+    """reference=True (golden generation): interp_add only for per_z, the one code for which the routine's ghost
+    refresh is well defined by the source.  Restriction and Galerkin product use the implementation's own
+    interpolation weights: they pin every weight that is ever read."""
+    name, nx, ny, nz, nst, ibc = case
+    sd = _seed(name)
+    per = pb.per3_of(ibc)
+    so = pb.periodic_random_op3(nx, ny, nz, nst, per, sd)
+    g = so.shape[1:]
+    gc = pb.coarse_shape(g)
+    out = {}
+    sor = np.zeros((2,) + g)
+    impl.setup_recip3(so, sor)
+    qf, q = pb.uniform(g, sd + 1, -1, 1), pb.uniform(g, sd + 2, -1, 1)
+    for ud in (DOWN, UP):
+        impl.relax3(so, qf, q, sor, ud, ibc=ibc)
+        out[f"relax{ud}"] = q.copy()
+    ci = np.zeros((26,) + gc)
+    impl.setup_interp3(so, ci, ibc=ibc)
+    out["interp_interior"] = ci[:, 1:-1, 1:-1, 1:-1].copy()
+    soc = np.zeros((14,) + gc)
+    impl.galerkin3(so, soc, ci, ibc=ibc)
+    out["galerkin"] = soc.copy()
+    r, qc = pb.uniform(g, sd + 3, -1, 1), np.zeros(gc)
+    impl.restrict3(r, qc, ci, ibc=ibc)
+    out["restrict_qc"], out["restrict_q"] = qc.copy(), r.copy()
+    if ibc == 5 or not reference:
+        x, xc, res = pb.uniform(g, sd + 4, -1, 1), pb.uniform(gc, sd + 5, -1, 1), pb.uniform(g, sd + 6, -1, 1)
+        pb.wrap3(xc, per)
+        impl.interp_add3(x, xc, so, res, ci, ibc=ibc)
+        out["interp_add_q"], out["interp_add_res"] = x.copy(), res.copy()
+    return out
+
+
+# dense coarsest-grid solves: the codes and extents for which the reference assembles the periodic operator
+# (per_x, per_y, per_z, per_yz; per_xy with nx = ny), oracle/boxmg3_per.c
+CG_PER3 = [("d3x3x3_x", 3, 3, 3, 2), ("d4x3x5_y", 4, 3, 5, 1), ("d3x4x4_z", 3, 4, 4, 5), ("d4x3x4_yz", 4, 3, 4, 7),
+           ("d4x4x3_xy", 4, 4, 3, 3), ("d5x4x3_x", 5, 4, 3, 2)]
+
+
+def coarse_solve_per3(impl, case):
+    name, nx, ny, nz, ibc = case
+    sd = _seed(name)
+    so = pb.periodic_random_op3(nx, ny, nz, 14, pb.per3_of(ibc), sd)
+    g = so.shape[1:]
+    n = nx * ny * nz
+    abd = np.zeros((n, n))
+    impl.setup_cg3(so, abd, ibc=ibc)
+    q = pb.uniform(g, sd + 2, -1, 1)
+    impl.solve_cg3(q, pb.uniform(g, sd + 1, -1, 1), abd, ibc=ibc)
+    return {"abd_upper": abd.T[np.triu_indices(n)].copy(), "q": q}
+
+
+def _per3(n, per, kind, seed=0):
+    if kind == "poisson":
+        return (lambda: pb.periodic_poisson3(n[0], n[1], n[2], per)), (lambda: pb.periodic_rhs3(n[0], n[1], n[2], per))
+    return (lambda: pb.periodic_random_op3(n[0], n[1], n[2], 14, per, seed)), (lambda: pb.periodic_rhs3(n[0], n[1], n[2], per))
+
+
+SOLVES_PER3 = {
+    # examples/basic-3d-ser/periodic.cc (seven-point Poisson, V-cycle, point relaxation) and wrapped random
+    # 27-point operators.  Goldens (reference kernels driven end to end) exist for per_z (ibc 5) only.
+    "perpoisson7_z_32_v21": _per3((32, 32, 32), (0, 0, 1), "poisson") + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=5),),
+    "perpoisson7_z_24x20x32_v11": _per3((24, 20, 32), (0, 0, 1), "poisson") + (dict(relax="point", nrelax_pre=1, nrelax_post=1, ibc=5),),
+    "perrand27_z_20x24x32_v21": _per3((20, 24, 32), (0, 0, 1), "random", 11) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=5),),
+    "perpoisson7_x_32_v21": _per3((32, 32, 32), (1, 0, 0), "poisson") + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=2),),
+    "perpoisson7_xy_32x32x24_v21": _per3((32, 32, 24), (1, 1, 0), "poisson") + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=3),),
+    "perrand27_y_24x32x20_v21": _per3((24, 32, 20), (0, 1, 0), "random", 12) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=1),),
+    "perrand27_xz_32x20x24_v21": _per3((32, 20, 24), (1, 0, 1), "random", 13) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=6),),
+    "perrand27_yz_20x32x32_v11": _per3((20, 32, 32), (0, 1, 1), "random", 14) + (dict(relax="point", nrelax_pre=1, nrelax_post=1, ibc=7),),
+    "perrand27_xyz_32_v21": _per3((32, 32, 32), (1, 1, 1), "random", 15) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=8),),
+}

@@ -263,3 +263,85 @@ def periodic_random_op(nx, ny, nst, per, seed):
         so[:, 0, :] = so[:, ny, :]
         so[:, ny + 1, :] = so[:, 1, :]
     return so
+
+
+def ibc3_of(per):
+    """(periodic_x, periodic_y, periodic_z) -> ibc of BMG_get_bc (src/2d/ftn/BMG_get_bc.f90:13-20 with
+    src/3d/ftn/BMG_parameters_f90.h:345-356)"""
+    return {(0, 0, 0): 0, (1, 0, 0): 2, (0, 1, 0): 1, (1, 1, 0): 3, (0, 0, 1): 5, (1, 0, 1): 6, (0, 1, 1): 7,
+            (1, 1, 1): 8}[tuple(int(bool(p)) for p in per)]
+
+
+def per3_of(ibc):
+    return {0: (0, 0, 0), 2: (1, 0, 0), 1: (0, 1, 0), 3: (1, 1, 0), 5: (0, 0, 1), 6: (1, 0, 1), 7: (0, 1, 1),
+            8: (1, 1, 1)}[ibc]
+
+
+def wrap3(a, per):
+    """periodic image into the ghost layers of a[..., k, j, i] (y, then x, then z, each over the full range of
+    the other two)"""
+    if per[1]:
+        a[..., :, 0, :] = a[..., :, -2, :]
+        a[..., :, -1, :] = a[..., :, 1, :]
+    if per[0]:
+        a[..., :, :, 0] = a[..., :, :, -2]
+        a[..., :, :, -1] = a[..., :, :, 1]
+    if per[2]:
+        a[..., 0, :, :] = a[..., -2, :, :]
+        a[..., -1, :, :] = a[..., 1, :, :]
+    return a
+
+
+def periodic_poisson3(nx, ny, nz, per):
+    """seven-point operator of examples/basic-3d-ser/periodic.cc:15-125 (create_op): mesh widths from n-1 in a
+    periodic direction, W / S / B entries also on the first column / row / plane there, ghost layers filled with
+    the periodic image (x, then y, then z)"""
+    so = np.zeros((4, nz + 2, ny + 2, nx + 2))
+    mx, my, mz = nx - (1 if per[0] else 0), ny - (1 if per[1] else 0), nz - (1 if per[2] else 0)
+    hx, hy, hz = 1.0 / (mx + 1), 1.0 / (my + 1), 1.0 / (mz + 1)
+    xh, yh, zh = hy * hz / hx, hx * hz / hy, hx * hy / hz
+    ibeg, jbeg, kbeg = (1 if per[0] else 2), (1 if per[1] else 2), (1 if per[2] else 2)
+    so[2, 1:nz + 1, jbeg:ny + 1, 1:nx + 1] = 1.0 * yh
+    so[1, 1:nz + 1, 1:ny + 1, ibeg:nx + 1] = 1.0 * xh
+    so[3, kbeg:nz + 1, 1:ny + 1, 1:nx + 1] = 1.0 * zh
+    so[0, 1:nz + 1, 1:ny + 1, 1:nx + 1] = 2.0 * xh + 2.0 * yh + 2.0 * zh
+    if per[0]:
+        so[:, :, :, 0] = so[:, :, :, nx]
+        so[:, :, :, nx + 1] = so[:, :, :, 1]
+    if per[1]:
+        so[:, :, 0, :] = so[:, :, ny, :]
+        so[:, :, ny + 1, :] = so[:, :, 1, :]
+    if per[2]:
+        so[:, 0, :, :] = so[:, nz, :, :]
+        so[:, nz + 1, :, :] = so[:, 1, :, :]
+    return so
+
+
+def periodic_rhs3(nx, ny, nz, per):
+    """set_problem of the same example (:128-193)"""
+    mx, my, mz = nx - (1 if per[0] else 0), ny - (1 if per[1] else 0), nz - (1 if per[2] else 0)
+    hx, hy, hz = 1.0 / (mx + 1), 1.0 / (my + 1), 1.0 / (mz + 1)
+    h2 = hx * hy * hz
+    b = np.zeros((nz + 2, ny + 2, nx + 2))
+    i = np.arange(1, nx + 1)[None, None, :]
+    j = np.arange(1, ny + 1)[None, :, None]
+    k = np.arange(1, nz + 1)[:, None, None]
+    b[1:-1, 1:-1, 1:-1] = (12 * (np.pi * np.pi) * np.sin(2 * np.pi * (i * hx)) * np.sin(2 * np.pi * (j * hy))
+                           * np.sin(2 * np.pi * (k * hz))) * h2
+    if per[0]:
+        b[:, :, 0] = b[:, :, nx]
+        b[:, :, nx + 1] = b[:, :, 1]
+    if per[1]:
+        b[:, 0, :] = b[:, ny, :]
+        b[:, ny + 1, :] = b[:, 1, :]
+    if per[2]:
+        b[0, :, :] = b[nz, :, :]
+        b[nz + 1, :, :] = b[1, :, :]
+    return b
+
+
+def periodic_random_op3(nx, ny, nz, nst, per, seed):
+    """strictly diagonally dominant random operator with the periodic image in the ghost layers of the wrapped
+    directions and zeros on Dirichlet sides"""
+    so = random_op((nz + 2, ny + 2, nx + 2), nst, seed)
+    return wrap3(so, per)

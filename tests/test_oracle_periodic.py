@@ -57,9 +57,3 @@ def test_periodic_solve_history_vs_golden(oracle, name):
     np.testing.assert_allclose(h, want, rtol=1e-10, atol=1e-12 if "line" in name else 1e-14)
     inner = x[1:-1, 1:-1]
     assert abs(float(np.sqrt(np.cumsum((inner * inner).ravel())[-1])) - float(gold["x_l2"])) <= 1e-11 * float(gold["x_l2"])
-
-
-def test_periodic_is_2d_only(oracle):
-    import problems as pb
-    with pytest.raises(ValueError):
-        oracle.ml_create(pb.fe3(8, 8, 8), ibc=2)
