@@ -205,46 +205,46 @@ class Kernels:
         nst, KK, JJ, II = so.shape
         lib.BMG3_SymStd_SETUP_recip(_p(so), _p(sor), u(II), u(JJ), u(KK), nst, 2)
 
-    def relax3(self, so, qf, q, sor, updown):
+    def relax3(self, so, qf, q, sor, updown, ibc=0):
         nst, KK, JJ, II = so.shape
-        lib.BMG3_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), nst, 2, 1, updown, 0)
+        lib.BMG3_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), nst, 2, 1, updown, ibc)
 
     def residual3(self, so, qf, q, res):
         nst, KK, JJ, II = so.shape
         lib.BMG3_SymStd_residual(1, 1, int(nst == 4), _p(q), _p(qf), _p(so), _p(res), u(II), u(JJ), u(KK), nst)
 
-    def restrict3(self, q, qc, ci):
+    def restrict3(self, q, qc, ci, ibc=0):
         KK, JJ, II = q.shape
         KKC, JJC, IIC = qc.shape
-        lib.BMG3_SymStd_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), 0)
+        lib.BMG3_SymStd_restrict(_p(q), _p(qc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), ibc)
 
-    def interp_add3(self, q, qc, so, res, ci):
+    def interp_add3(self, q, qc, so, res, ci, ibc=0):
         KK, JJ, II = q.shape
         KKC, JJC, IIC = qc.shape
-        lib.BMG3_SymStd_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK), so.shape[0], 0)
+        lib.BMG3_SymStd_interp_add(_p(q), _p(qc), _p(so), _p(res), _p(ci), u(IIC), u(JJC), u(KKC), u(II), u(JJ), u(KK), so.shape[0], ibc)
 
-    def setup_interp3(self, so, ci):
+    def setup_interp3(self, so, ci, ibc=0):
         nst, KK, JJ, II = so.shape
         _, KKC, JJC, IIC = ci.shape
         lib.BMG3_SymStd_SETUP_interp_OI(_p(so), None, _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC),
-                                        int(nst == 4), nst, 1, 0, None)
+                                        int(nst == 4), nst, 1, ibc, None)
 
-    def galerkin3(self, so, soc, ci):
+    def galerkin3(self, so, soc, ci, ibc=0):
         nst, KK, JJ, II = so.shape
         _, KKC, JJC, IIC = ci.shape
         f = lib.BMG3_SymStd_SETUP_ITLI07_ex if nst == 4 else lib.BMG3_SymStd_SETUP_ITLI27_ex
-        f(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), 0)
+        f(_p(so), _p(soc), _p(ci), u(II), u(JJ), u(KK), u(IIC), u(JJC), u(KKC), ibc)
 
-    def setup_cg3(self, so, abd):
+    def setup_cg3(self, so, abd, ibc=0):
         nst, KK, JJ, II = so.shape
         n2, n1 = abd.shape
-        lib.BMG3_SymStd_SETUP_cg_LU(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2), 0)
+        lib.BMG3_SymStd_SETUP_cg_LU(_p(so), u(II), u(JJ), u(KK), nst, _p(abd), u(n1), u(n2), ibc)
 
-    def solve_cg3(self, q, qf, abd):
+    def solve_cg3(self, q, qf, abd, ibc=0):
         KK, JJ, II = q.shape
         n2, n1 = abd.shape
         bbd = np.zeros(n2)
-        lib.BMG3_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2), 0)
+        lib.BMG3_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2), ibc)
 
     def l2(self, v):
         return l2norm(v)

@@ -96,13 +96,32 @@ static int bc2(int jpn, const char *who)
 	return -1;
 }
 
-static bool dirichlet(int jpn, const char *who)
+// 3D boundary code of BMG_get_bc (0, 1 y, 2 x, 3 xy, 5 z, 6 xz, 7 yz, 8 xyz); the indefinite (negative) codes
+// and -4 are not implemented
+static bool bc3(int jpn, const char *who)
 {
-	if (jpn == 0) return true;
+	if (jpn >= 0 && periodic3_code_ok(jpn)) return true;
 	char buf[200];
-	snprintf(buf, sizeof(buf), "%s: only Dirichlet boundaries (ibc = 0) are implemented on the GPU path, got %d", who, jpn);
+	snprintf(buf, sizeof(buf), "%s: boundary code %d is not implemented on the GPU path (0 and the definite periodic codes are)",
+	         who, jpn);
 	report(buf);
 	return false;
+}
+
+// the periodic interpolation set-up and Galerkin product coarsen a periodic direction by pairs: its extent must
+// be even (the reference's example uses even extents; odd ones are refused rather than guessed)
+static bool even_periodic(int ipn, len_t iif, len_t jjf, len_t kkf, const char *who)
+{
+	const bool px = ipn == 2 || ipn == 3 || ipn == 6 || ipn == 8, py = ipn == 1 || ipn == 3 || ipn == 7 || ipn == 8,
+	           pz = ipn >= 5 && ipn <= 8;
+	if ((px && (iif & 1)) || (py && (jjf & 1)) || (pz && (kkf & 1))) {
+		char buf[200];
+		snprintf(buf, sizeof(buf), "%s: a periodic direction needs an even extent (got %u x %u x %u, code %d)", who,
+		         (unsigned)iif - 2, (unsigned)jjf - 2, (unsigned)kkf - 2, ipn);
+		report(buf);
+		return false;
+	}
+	return true;
 }
 
 } // namespace cedar_amd
@@ -520,14 +539,17 @@ void BMG3_SymStd_relax_GS(int kg, real_t *so, real_t *qf, real_t *q, real_t *sor
                           int irelax_sym, int updown, int jpn)
 {
 	(void)kg; (void)nsorv;
-	if (!dirichlet(jpn, "BMG3_SymStd_relax_GS")) return;
+	if (!bc3(jpn, "BMG3_SymStd_relax_GS")) return;
 	size_t P = (size_t)ii * jj * kk;
 	int nst_eff = (ifd != 1) ? 14 : 4;
 	if (nst_eff > nstncl) nst_eff = nstncl;
 	// NONSYM always sweeps in the UP order in 3D (relax_GS.f90:85-94)
 	int ud = (irelax_sym == 0) ? BMG_UP : updown;
 	Staged sso(so, P * nstncl, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
-	relax3_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, nst_eff, ud, current_stream());
+	if (jpn)
+		relax3_gs_per(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, nst_eff, ud, jpn, current_stream());
+	else
+		relax3_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, nst_eff, ud, current_stream());
 }
 
 void BMG3_SymStd_residual(int kg, int NOG, int ifd, real_t *q, real_t *qf, real_t *so, real_t *RES,
@@ -543,22 +565,30 @@ void BMG3_SymStd_residual(int kg, int NOG, int ifd, real_t *q, real_t *qf, real_
 void BMG3_SymStd_restrict(real_t *q, real_t *qc, real_t *ci, len_t nx, len_t ny, len_t nz,
                           len_t nxc, len_t nyc, len_t nzc, int jpn)
 {
-	if (!dirichlet(jpn, "BMG3_SymStd_restrict")) return;
+	if (!bc3(jpn, "BMG3_SymStd_restrict")) return;
 	size_t P = (size_t)nx * ny * nz, PC = (size_t)nxc * nyc * nzc;
-	Staged sq(q, P, true, false), sqc(qc, PC, true, true), sci(ci, PC * 26, true, false);
-	restrict3(sq.get(), sqc.get(), sci.get(), (int)nx, (int)ny, (int)nz, (int)nxc, (int)nyc, (int)nzc, current_stream());
+	// periodic: the fine vector gets its ghosts refreshed first (restrict.f90:78-103), so it is an output too
+	Staged sq(q, P, true, jpn != 0), sqc(qc, PC, true, true), sci(ci, PC * 26, true, false);
+	if (jpn)
+		restrict3_per(sq.get(), sqc.get(), sci.get(), (int)nx, (int)ny, (int)nz, (int)nxc, (int)nyc, (int)nzc, jpn, current_stream());
+	else
+		restrict3(sq.get(), sqc.get(), sci.get(), (int)nx, (int)ny, (int)nz, (int)nxc, (int)nyc, (int)nzc, current_stream());
 }
 
 void BMG3_SymStd_interp_add(real_t *q, real_t *qc, real_t *so, real_t *res, real_t *ci,
                             len_t iic, len_t jjc, len_t kkc, len_t iif, len_t jjf, len_t kkf,
                             int NStncl, int jpn)
 {
-	if (!dirichlet(jpn, "BMG3_SymStd_interp_add")) return;
+	if (!bc3(jpn, "BMG3_SymStd_interp_add")) return;
 	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
 	Staged sq(q, P, true, true), sqc(qc, PC, true, false), sso(so, P * NStncl, true, false),
 	    sr(res, P, true, true), sci(ci, PC * 26, true, false);
-	interp_add3(sq.get(), sqc.get(), sso.get(), sr.get(), sci.get(), (int)iic, (int)jjc, (int)kkc,
-	            (int)iif, (int)jjf, (int)kkf, current_stream());
+	if (jpn)
+		interp_add3_per(sq.get(), sqc.get(), sso.get(), sr.get(), sci.get(), (int)iic, (int)jjc, (int)kkc,
+		                (int)iif, (int)jjf, (int)kkf, jpn, current_stream());
+	else
+		interp_add3(sq.get(), sqc.get(), sso.get(), sr.get(), sci.get(), (int)iic, (int)jjc, (int)kkc,
+		            (int)iif, (int)jjf, (int)kkf, current_stream());
 }
 
 void BMG3_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
@@ -566,20 +596,27 @@ void BMG3_SymStd_SETUP_interp_OI(real_t *so, real_t *soc, real_t *ci, len_t iif,
                                  int jpn, real_t *yo)
 {
 	(void)soc; (void)irelax; (void)yo;
-	if (!dirichlet(jpn, "BMG3_SymStd_SETUP_interp_OI")) return;
+	if (!bc3(jpn, "BMG3_SymStd_SETUP_interp_OI") || !even_periodic(jpn, iif, jjf, kkf, "BMG3_SymStd_SETUP_interp_OI")) return;
 	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
 	Staged sso(so, P * nstncl, true, false), sci(ci, PC * 26, true, true);
-	setup_interp3(sso.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc, ifd, current_stream());
+	if (jpn)
+		setup_interp3_per(sso.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc, ifd, jpn, current_stream());
+	else
+		setup_interp3(sso.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc, ifd, current_stream());
 }
 
 static void itli3(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
                   len_t iic, len_t jjc, len_t kkc, int ipn, int nst)
 {
-	if (!dirichlet(ipn, "BMG3_SymStd_SETUP_ITLI_ex")) return;
+	if (!bc3(ipn, "BMG3_SymStd_SETUP_ITLI_ex") || !even_periodic(ipn, iif, jjf, kkf, "BMG3_SymStd_SETUP_ITLI_ex")) return;
 	size_t P = (size_t)iif * jjf * kkf, PC = (size_t)iic * jjc * kkc;
 	Staged sso(so, P * nst, true, false), ssoc(soc, PC * 14, true, true), sci(ci, PC * 26, true, false);
-	galerkin3(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc,
-	          nst == 4, current_stream());
+	if (ipn)
+		galerkin3_per(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc,
+		              nst == 4, ipn, current_stream());
+	else
+		galerkin3(sso.get(), ssoc.get(), sci.get(), (int)iif, (int)jjf, (int)kkf, (int)iic, (int)jjc, (int)kkc,
+		          nst == 4, current_stream());
 }
 
 void BMG3_SymStd_SETUP_ITLI07_ex(real_t *so, real_t *soc, real_t *ci, len_t iif, len_t jjf, len_t kkf,
@@ -597,15 +634,22 @@ void BMG3_SymStd_SETUP_ITLI27_ex(real_t *so, real_t *soc, real_t *ci, len_t iif,
 void BMG3_SymStd_SETUP_cg_LU(real_t *so, len_t ii, len_t jj, len_t kk, int NStncl, real_t *abd,
                              len_t nabd1, len_t nabd2, int ibc)
 {
-	if (!dirichlet(ibc, "BMG3_SymStd_SETUP_cg_LU")) return;
-	if (NStncl != 14 && NStncl != 4) {
+	if (!bc3(ibc, "BMG3_SymStd_SETUP_cg_LU")) return;
+	if ((NStncl != 14 && NStncl != 4) || (ibc && NStncl != 14)) { // the periodic branch knows 14 only (:235, :596)
 		report("Cholesky decomp failed! (incorrect NStncl)");
 		return;
 	}
 	size_t P = (size_t)ii * jj * kk, NA = (size_t)nabd1 * nabd2;
+	if (ibc && ((size_t)nabd1 < (size_t)(ii - 2) * (jj - 2) * (kk - 2) || (size_t)nabd2 < (size_t)(ii - 2) * (jj - 2) * (kk - 2))) {
+		report("BMG3_SymStd_SETUP_cg_LU: the periodic coarsest operator is dense, ABD(n,n) (include/cedar/3d/solver.h:118-121)");
+		return;
+	}
 	Staged sso(so, P * NStncl, true, false), sabd(abd, NA, true, true);
 	int *dinfo = static_cast<int *>(pool_get(64));
-	setup_cg3(sso.get(), (int)ii, (int)jj, (int)kk, NStncl, sabd.get(), (int)nabd1, (int)nabd2, dinfo, current_stream());
+	if (ibc)
+		setup_cg3_per(sso.get(), (int)ii, (int)jj, (int)kk, sabd.get(), (int)nabd1, ibc, dinfo, current_stream());
+	else
+		setup_cg3(sso.get(), (int)ii, (int)jj, (int)kk, NStncl, sabd.get(), (int)nabd1, (int)nabd2, dinfo, current_stream());
 	cg_info(dinfo, "Coarse grid Cholesky decomp failed!");
 	pool_put(dinfo, 64);
 }
@@ -613,10 +657,13 @@ void BMG3_SymStd_SETUP_cg_LU(real_t *so, len_t ii, len_t jj, len_t kk, int NStnc
 void BMG3_SymStd_SOLVE_cg(real_t *q, real_t *qf, len_t ii, len_t jj, len_t kk, real_t *abd,
                           real_t *bbd, len_t nabd1, len_t nabd2, int ibc)
 {
-	if (!dirichlet(ibc, "BMG3_SymStd_SOLVE_cg")) return;
+	if (!bc3(ibc, "BMG3_SymStd_SOLVE_cg")) return;
 	size_t P = (size_t)ii * jj * kk, NA = (size_t)nabd1 * nabd2;
 	Staged sq(q, P, true, true), sqf(qf, P, true, false), sabd(abd, NA, true, false), sb(bbd, nabd2, false, true);
-	solve_cg3(sq.get(), sqf.get(), (int)ii, (int)jj, (int)kk, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
+	if (ibc)
+		solve_cg3_per(sq.get(), sqf.get(), (int)ii, (int)jj, (int)kk, sabd.get(), sb.get(), (int)nabd1, ibc, current_stream());
+	else
+		solve_cg3(sq.get(), sqf.get(), (int)ii, (int)jj, (int)kk, sabd.get(), sb.get(), (int)nabd1, (int)nabd2, current_stream());
 }
 
 } // extern "C"

@@ -130,6 +130,24 @@ void galerkin2_per(const real_t *so, real_t *soc, const real_t *ci, int IIF, int
 void setup_interp2_per(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, int ipn, hipStream_t st);
 void setup_cg2_per(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int ipn, int *info, hipStream_t st);
 void solve_cg2_per(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int ipn, hipStream_t st);
+// 3D periodic boundary conditions (periodic3d.hip, relax3d.hip); ipn = 1 y, 2 x, 3 xy, 5 z, 6 xz, 7 yz, 8 xyz
+bool periodic3_code_ok(int ipn);
+void wrap3(real_t *a, int II, int JJ, int KK, int narrays, int ipn, hipStream_t st);
+void wrap3_colour(real_t *q, int II, int JJ, int KK, int jb, int kb, int ipn, hipStream_t st);
+void wrap3_sweep_end(real_t *q, int II, int JJ, int KK, int ipn, hipStream_t st);
+void relax3_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int KK, int nstncl, int updown, int ipn, hipStream_t st);
+void restrict3_per(real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int KK, int IIC, int JJC, int KKC, int ipn,
+                   hipStream_t st);
+void interp_add3_per(real_t *q, const real_t *qc, const real_t *so, real_t *res, const real_t *ci,
+                     int IIC, int JJC, int KKC, int IIF, int JJF, int KKF, int ipn, hipStream_t st);
+void setup_interp3_per(const real_t *so, real_t *ci, int IIF, int JJF, int KKF, int IIC, int JJC, int KKC, int ifd, int ipn,
+                       hipStream_t st);
+void galerkin3_per(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF, int IIC, int JJC, int KKC,
+                   int ifd, int ipn, hipStream_t st);
+void setup_cg3_per(const real_t *so, int II, int JJ, int KK, real_t *abd, int nabd1, int ipn, int *info, hipStream_t st);
+void solve_cg3_per(real_t *q, const real_t *qf, int II, int JJ, int KK, const real_t *abd, real_t *bbd, int nabd1, int ipn,
+                   hipStream_t st);
 // qf = A q (operator application with Cedar's sign convention), residual.hip
 void matvec2(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int nstncl, hipStream_t st);
 void matvec3(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int KK, int nstncl, hipStream_t st);

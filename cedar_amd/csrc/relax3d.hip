@@ -880,4 +880,37 @@ void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 	}
 }
 
+// Periodic sweep (BMG3_SymStd_relax_GS.f90:188-357): the colours of the Dirichlet sweep, one launch each, every
+// colour followed by the ghost refreshes the reference performs while it walks that colour (x ghosts of a row when
+// the row is done, y ghosts of a plane when the plane is done; points of one colour never read each other nor a
+// ghost refreshed under the same colour, so refreshing after the launch gives the same values), the z ghost planes
+// only once the sweep is over (:279-286) -- until then they hold the previous sweep's values, as in the reference.
+void relax3_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
+                   int II, int JJ, int KK, int nstncl, int updown, int ipn, hipStream_t st)
+{
+	if (II < 3 || JJ < 3 || KK < 3) return;
+	const bool up = (updown == BMG_UP);
+	if (nstncl == 14) {
+		const Op3 A = op3_cedar(so, sor, II, JJ, KK);
+		for (int c = 0; c < 8; c++) {
+			const int pts = up ? c : 7 - c;
+			const int ib = pts & 1, jb = (pts >> 1) & 1, kb = (pts >> 2) & 1;
+			const int ni = (II - 2 - ib + 1) / 2, nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+			if (nj <= 0 || nk <= 0) continue;
+			if (ni > 0)
+				hipLaunchKernelGGL(relax27_colour, dim3(cap_grid((size_t)ni * nj * nk, 256)), dim3(256), 0, st,
+				                   A, qf, q, II, JJ, KK, ib, jb, kb);
+			wrap3_colour(q, II, JJ, KK, jb, kb, ipn, st);
+		}
+	} else {
+		for (int c = 0; c < 2; c++) {
+			const int pts = up ? c : 1 - c;
+			const size_t n = (size_t)((II - 2 + 1) / 2) * (JJ - 2) * (KK - 2);
+			hipLaunchKernelGGL(relax7_colour, dim3(cap_grid(n, 256)), dim3(256), 0, st, so, qf, q, sor, II, JJ, KK, pts);
+			wrap3_colour(q, II, JJ, KK, -1, -1, ipn, st);
+		}
+	}
+	wrap3_sweep_end(q, II, JJ, KK, ipn, st);
+}
+
 } // namespace cedar_amd

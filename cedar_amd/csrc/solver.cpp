@@ -171,6 +171,10 @@ void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int 
 void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *b, int updown, int n, hipStream_t st)
 {
 	for (int it = 0; it < n; it++) {
+		if (s->nd == 3 && s->st.ibc) {
+			relax3_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, s->st.ibc, st);
+			continue;
+		}
 		if (s->nd == 3) {
 			if (L.Ailv) relax3_gs27_op(op3_ilv(L.Ailv, L.II, L.JJ, L.KK), b, x, L.II, L.JJ, L.KK, updown, st);
 			else relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
@@ -202,6 +206,7 @@ void coarse_solve(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t s
 	const Level &C = s->lv.back();
 	if (s->nd == 2 && s->st.ibc) solve_cg2_per(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->st.ibc, st);
 	else if (s->nd == 2) solve_cg2(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
+	else if (s->st.ibc) solve_cg3_per(x, b, C.II, C.JJ, C.KK, s->ABD, s->bbd, s->nabd1, s->st.ibc, st);
 	else solve_cg3(x, b, C.II, C.JJ, C.KK, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
 }
 
@@ -213,12 +218,14 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	residual(s, L, x, b, L.res, st);
 	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
 	else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	else if (s->st.ibc) restrict3_per(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, s->st.ibc, st);
 	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
 	clear(K.x, K.npts, st); // coarse_x.set(0.0)
 	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
 	else ncycle(s, lvl + 1, K.x, K.b, st);
 	if (s->nd == 2 && s->st.ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, s->st.ibc, st);
 	else if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	else if (s->st.ibc) interp_add3_per(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, s->st.ibc, st);
 	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
 	smooth(s, L, x, b, BMG_UP, s->st.nrelax_post, st);
 }
@@ -318,12 +325,15 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		s->st.relaxation = CEDAR_AMD_RELAX_POINT;
 	}
 	if (s->st.ibc != 0) {
-		// periodic boundary conditions: 2D, V-cycle; point relaxation keeps a row in the default LDS window
-		const bool ok = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3 && s->st.cycle == 0
-		                && (s->st.relaxation != CEDAR_AMD_RELAX_POINT || (size_t)(nx + 2) * sizeof(real_t) <= 64 * 1024);
-		if (!ok) {
-			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for 2D V-cycles "
-			             "(ibc 1..3; point relaxation: rows up to 8190 points); no solver created";
+		// periodic boundary conditions: V-cycle.  2D: ibc 1..3, point relaxation keeps a row in the default LDS
+		// window; 3D: ibc 1..3, 5..8 (BMG_get_bc.f90:13-20), even extents in the periodic directions on every level
+		// that is coarsened (checked below, once the level sizes are known)
+		const bool ok2 = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3 && s->st.cycle == 0
+		                 && (s->st.relaxation != CEDAR_AMD_RELAX_POINT || (size_t)(nx + 2) * sizeof(real_t) <= 64 * 1024);
+		const bool ok3 = nd == 3 && s->st.ibc > 0 && periodic3_code_ok(s->st.ibc) && s->st.cycle == 0;
+		if (!ok2 && !ok3) {
+			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for V-cycles "
+			             "(2D: ibc 1..3, point relaxation: rows up to 8190 points; 3D: ibc 1..3, 5..8); no solver created";
 			print_error(msg);
 			delete s;
 			return nullptr;
@@ -363,7 +373,22 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	const Level &C = s->lv.back();
 	// periodic: the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)
 	if (nd == 2) { s->nabd1 = s->st.ibc ? C.nx * C.ny : C.nx + 2; s->nabd2 = C.nx * C.ny; }
-	else { s->nabd1 = C.nx * (C.ny + 1) + 2; s->nabd2 = C.nx * C.ny * C.nz; }
+	else { s->nabd1 = s->st.ibc ? C.nx * C.ny * C.nz : C.nx * (C.ny + 1) + 2; s->nabd2 = C.nx * C.ny * C.nz; } // 3d/solver.h:118-121
+	if (nd == 3 && s->st.ibc) {
+		const int c = s->st.ibc;
+		const bool px = c == 2 || c == 3 || c == 6 || c == 8, py = c == 1 || c == 3 || c == 7 || c == 8, pz = c >= 5;
+		bool ok = (size_t)s->nabd2 <= 8192; // dense factor: n^2 doubles, one workgroup
+		for (int l = 0; l + 1 < nlev; l++)
+			ok = ok && !(px && (s->lv[l].nx & 1)) && !(py && (s->lv[l].ny & 1)) && !(pz && (s->lv[l].nz & 1));
+		if (!ok) {
+			char msg[] = "cedar_amd_solver_create: 3D periodic boundary conditions need an even extent in every periodic "
+			             "direction on each level that is coarsened (choose the extents or num_levels accordingly) and at "
+			             "most 8192 unknowns on the coarsest level; no solver created";
+			print_error(msg);
+			cedar_amd_solver_destroy(s); // releases the levels allocated so far
+			return nullptr;
+		}
+	}
 	s->ABD = dalloc((size_t)s->nabd1 * s->nabd2);
 	s->bbd = dalloc(s->nabd2);
 	s->red = dalloc(4100);
@@ -405,10 +430,15 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 			}
 		} else {
 			int ifd = F.nst == 4;
-			setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
-			galerkin3(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
+			if (s->st.ibc) {
+				setup_interp3_per(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, s->st.ibc, st);
+				galerkin3_per(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, s->st.ibc, st);
+			} else {
+				setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
+				galerkin3(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
+			}
 			setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, F.KK, st);
-			if (F.nst == 14 && ilv_wanted(F)) {
+			if (F.nst == 14 && !s->st.ibc && ilv_wanted(F)) {
 				F.Ailv = dalloc_raw(ilv_doubles(F.II, F.JJ, F.KK));
 				ilv_build(F.A, F.SOR0 + F.npts, F.Ailv, F.II, F.JJ, F.KK, st);
 			}
@@ -416,6 +446,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	}
 	if (nd == 2 && s->st.ibc) setup_cg2_per(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->st.ibc, s->dinfo, st);
 	else if (nd == 2) setup_cg2(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
+	else if (s->st.ibc) setup_cg3_per(C.A, C.II, C.JJ, C.KK, s->ABD, s->nabd1, s->st.ibc, s->dinfo, st);
 	else setup_cg3(C.A, C.II, C.JJ, C.KK, C.nst, s->ABD, s->nabd1, s->nabd2, s->dinfo, st);
 	int info = 0;
 	CEDAR_HIP_CHECK(hipMemcpyAsync(&info, s->dinfo, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -11,8 +11,12 @@
  *    pointer obtained from cedar_amd_malloc/hipMalloc (operated on in place).
  *    Linking Cedar against libcedar_amd.so instead of its Fortran objects
  *    therefore routes the whole hot path to the GPU without source changes.
- *    Only Dirichlet boundaries (per_mask = 0, ibc = BMG_BCs_definite) are
- *    implemented; other values report through print_error and return.
+ *    Boundary codes (jpn / ibc, what BMG_get_bc returns for grid.periodic): 0 definite and the definite
+ *    periodic codes -- 2D 1 (y), 2 (x), 3 (xy); 3D also 5 (z), 6 (xz), 7 (yz), 8 (xyz), with even extents in the
+ *    periodic directions for the two 3D set-up routines.  The indefinite codes (< 0) report through print_error
+ *    and return.  3D: where the reference's periodic Fortran is not self-consistent (the ghost loops of
+ *    BMG3_SymStd_interp_add.f90:253-272, dense-matrix entries of SETUP_cg_LU for xz / xyz / xy with nx != ny) the
+ *    library applies the periodic operator itself; DESIGN.md section 6 has the evidence.
  *
  * 2. Handle API.  Device-resident hierarchy, modelled on Cedar's own C
  *    interface (include/cedar/2d/interface/c/solver.h: bmg2_solver_create /
@@ -222,7 +226,8 @@ typedef struct {
 	int min_coarse;   /* solver.min_coarse (3) :43 */
 	int cycle;        /* solver.cycle.type: 0 = "v" (default), 1 = "f" (include/cedar/cycle/fcycle.h:49-83) :30-36 */
 	int ibc;          /* boundary code of BMG_get_bc(per_mask) from grid.periodic (src/kernel_params.cc): 0 definite,
-	                     1 periodic in y, 2 in x, 3 in both (2D, V-cycle) */
+	                     1 periodic in y, 2 in x, 3 in xy; 3D also 5 z, 6 xz, 7 yz, 8 xyz (V-cycle; 3D: even extents in
+	                     the periodic directions on every level that is coarsened) */
 } cedar_amd_settings;
 
 void cedar_amd_default_settings(cedar_amd_settings *s);

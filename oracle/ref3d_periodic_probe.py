@@ -46,3 +46,58 @@ for ibc, name in ((2, "per_x"), (1, "per_y"), (5, "per_z"), (8, "per_xyz")):
     print("BMG3_SymStd_interp_add, %dx%dx%d, boundary code %d (%s): guard plane touched: %s" % (nx, ny, nz, ibc, name, bool(np.any(buf[-1] != 0))))
     for what, ok, changed, total in chk:
         print("    %-16s wrapped completely: %-5s  ghost cells the call changed: %d of %d" % (what, ok, changed, total))
+
+# ---------------------------------------------------------------------------------------------------------------
+# 2. BMG3_SymStd_SETUP_cg_LU, periodic branch (:200-619): the dense matrix the reference factors, rebuilt from its
+#    Cholesky factor (U^T U), against the periodic operator assembled by walking the stencil (oracle/boxmg3_per.c).
+# ---------------------------------------------------------------------------------------------------------------
+from pyoracle import Oracle  # noqa: E402
+
+O = Oracle()
+print()
+print("BMG3_SymStd_SETUP_cg_LU: entries of the factored dense matrix that are not the periodic operator's")
+print("    (upper triangle; tolerance 1e-12; random 27-point operator with periodic ghost layers)")
+for per in [(1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1), (1, 1, 0), (1, 0, 1), (1, 1, 1)]:
+    row = []
+    for n in [(4, 4, 4), (3, 3, 3), (4, 6, 4), (5, 4, 4), (4, 4, 5), (8, 8, 8)]:
+        ibc = pb.ibc3_of(per)
+        so = pb.periodic_random_op3(n[0], n[1], n[2], 14, per, 9)
+        N = n[0] * n[1] * n[2]
+        a_ref, a_orc = np.zeros((N, N)), np.zeros((N, N))
+        R.setup_cg3(so, a_ref, ibc=ibc)
+        O.setup_cg3(so, a_orc, ibc=ibc)
+        Ur, Uo = np.triu(a_ref.T), np.triu(a_orc.T)
+        bad = np.argwhere(np.triu(np.abs(Ur.T @ Ur - Uo.T @ Uo)) > 1e-12)
+        row.append("%dx%dx%d: %d" % (n + (len(bad),)))
+    print("    code %d %-8s %s" % (ibc, "per_" + "".join(c for c, p in zip("xyz", per) if p), "   ".join(row)))
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3. BMG3_SymStd_SETUP_interp_OI, periodic branch (:808-2811): weights against the restatement (Dirichlet formulas,
+#    loops started one coarse point earlier in a periodic direction, ghost refresh after every phase).  Compared
+#    through what reads them: restriction of a random vector and the Galerkin product, both computed by the oracle
+#    from the two sets of weights.
+# ---------------------------------------------------------------------------------------------------------------
+print()
+print("BMG3_SymStd_SETUP_interp_OI: do the reference's weights restrict / coarsen like the restatement's?")
+print("    (27-point; 'yes' = restriction of a random vector bit-identical and Galerkin product bit-identical)")
+for per in [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]:
+    row = []
+    for n in [(8, 10, 12), (6, 4, 8), (12, 6, 10), (8, 8, 8), (16, 8, 4), (8, 6, 4), (10, 8, 6), (9, 8, 8)]:
+        ibc = pb.ibc3_of(per)
+        so = pb.periodic_random_op3(n[0], n[1], n[2], 14, per, 3)
+        g = so.shape[1:]
+        gc = pb.coarse_shape(g)
+        c1, c2 = np.zeros((26,) + gc), np.zeros((26,) + gc)
+        R.setup_interp3(so, c1, ibc=ibc)
+        O.setup_interp3(so, c2, ibc=ibc)
+        r = pb.uniform(g, 7, -1, 1)
+        q1, q2 = np.zeros(gc), np.zeros(gc)
+        O.restrict3(r.copy(), q1, c1, ibc=ibc)
+        O.restrict3(r.copy(), q2, c2, ibc=ibc)
+        s1, s2 = np.zeros((14,) + gc), np.zeros((14,) + gc)
+        O.galerkin3(so, s1, c1, ibc=ibc)
+        O.galerkin3(so, s2, c2, ibc=ibc)
+        row.append("%dx%dx%d: %s" % (n + ("yes" if np.array_equal(q1, q2) and np.array_equal(s1, s2) else "NO",)))
+    print("    code %d %-8s %s" % (ibc, "per_" + "".join(c for c, p in zip("xyz", per) if p), "  ".join(row)))
+print("    -> agreement needs ny <= nz (the branch mixes up the y and z extents) and even extents in the periodic")
+print("       directions (9x8x8 with x periodic: the reference pairs the two end points through the wrap; refused here).")

@@ -100,11 +100,13 @@ def test_examples_end_to_end(tmp_path):
     ex = os.path.join(ROOT, "examples")
     subprocess.run(["make", "-C", ex], check=True, capture_output=True)
     json.dump({"grid": {"n": [200, 200]}}, open(tmp_path / "config.json", "w"))
-    with open(os.path.join(ex, "periodic-config.json")) as f:
-        open(tmp_path / "periodic-config.json", "w").write(f.read())
+    for cfg in ("periodic-config.json", "periodic-config-3d.json"):
+        with open(os.path.join(ex, cfg)) as f:
+            open(tmp_path / cfg, "w").write(f.read())
     d3 = tmp_path / "d3"  # no config.json there: the 3D example's default 64^3 grid
     d3.mkdir()
-    for exe, args in (("ser-poisson-2d", []), ("ser-poisson-3d", []), ("ser-periodic-2d", []), ("capi-poisson-2d", ["200"])):
+    for exe, args in (("ser-poisson-2d", []), ("ser-poisson-3d", []), ("ser-periodic-2d", []), ("ser-periodic-3d", []),
+                      ("capi-poisson-2d", ["200"])):
         p = subprocess.run([os.path.join(ex, exe)] + args, cwd=d3 if exe == "ser-poisson-3d" else tmp_path,
                            capture_output=True, text=True)
         assert p.returncode == 0, (exe, p.stdout[-400:], p.stderr[-400:])

@@ -190,9 +190,8 @@ def test_device_pointers_are_used_in_place(K):
 
 
 def test_unserved_boundary_codes_are_refused_loudly(K, capfd):
-    """boundary codes the GPU path does not serve (indefinite variants < 0, 3D periodic codes) report
-    through print_error and leave q untouched; the 2D periodic codes 1..3 are served
-    (tests/test_gpu_periodic.py)"""
+    """boundary codes the GPU path does not serve (the indefinite variants < 0) report through print_error and
+    leave q untouched; the definite periodic codes are served (tests/test_gpu_periodic.py, test_gpu_periodic3d.py)"""
     import ctypes as C
     from cedar_amd import capi
     import problems as pb
@@ -209,9 +208,9 @@ def test_unserved_boundary_codes_are_refused_loudly(K, capfd):
     q30 = q3.copy()
     sor3, qf3 = np.zeros((2,) + g3), np.zeros(g3)
     capi.lib.BMG3_SymStd_relax_GS(1, capi._p(so3), capi._p(qf3), capi._p(q3), capi._p(sor3), C.c_uint(6), C.c_uint(6), C.c_uint(6),
-                                  0, 14, 2, 1, 0, 8)
+                                  0, 14, 2, 1, 0, -8)
     assert np.array_equal(q3, q30)
-    assert "Dirichlet" in capfd.readouterr().err
+    assert "boundary code -8 is not implemented" in capfd.readouterr().err
 
 
 @pytest.mark.parametrize("shape,nst", [((9, 8, 7), 14), ((13, 9, 10), 4), ((33, 20, 17), 14), ((17, 12, 31), 4)], ids=str)

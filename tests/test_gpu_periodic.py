@@ -85,7 +85,7 @@ def test_periodic_solver_refuses_what_it_does_not_serve(capfd):
     from cedar_amd import capi
     with pytest.raises(RuntimeError):
         capi.Solver(pb.periodic_poisson2(32, 32, (True, False)), cycle="f", ibc=2)
-    assert "periodic boundary conditions are implemented for 2D V-cycles" in capfd.readouterr().err
+    assert "periodic boundary conditions are implemented for V-cycles" in capfd.readouterr().err
 
 
 def test_periodic_long_lines(K, oracle):
