@@ -164,7 +164,8 @@ real_t orc_l2_norm3(const real_t *v, len_t II, len_t JJ, len_t KK);
 real_t orc_inf_norm3(const real_t *v, len_t II, len_t JJ, len_t KK);
 
 /* ---- multilevel driver (mlsolve.c) ---- */
-enum { ORC_RELAX_POINT = 0, ORC_RELAX_LINE_X = 1, ORC_RELAX_LINE_Y = 2, ORC_RELAX_LINE_XY = 3 };
+enum { ORC_RELAX_POINT = 0, ORC_RELAX_LINE_X = 1, ORC_RELAX_LINE_Y = 2, ORC_RELAX_LINE_XY = 3,
+       ORC_RELAX_PLANE_XY = 4, ORC_RELAX_PLANE_XZ = 5, ORC_RELAX_PLANE_YZ = 6, ORC_RELAX_PLANE_XYZ = 7 };
 
 typedef struct orc_ml orc_ml;
 
@@ -175,7 +176,18 @@ orc_ml *orc_ml_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const 
 orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
                          int relax, int nrelax_pre, int nrelax_post, int min_coarse,
                          int num_levels, int ibc);
+orc_ml *orc_ml_create_ex(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                         int relax, int nrelax_pre, int nrelax_post, int min_coarse,
+                         int num_levels, int ibc, const int *plane_cfg, real_t plane_tol);
 void orc_ml_destroy(orc_ml *ml);
+
+/* ---- plane relaxation (planes.c) ---- */
+typedef struct orc_planes orc_planes;
+orc_planes *orc3_planes_create(int dir, const real_t *so, len_t II, len_t JJ, len_t KK, int nst, const int *cfg, real_t tol);
+void orc3_planes_destroy(orc_planes *p);
+void orc3_plane_rhs(int dir, int nst, const real_t *so, const real_t *x, const real_t *b, real_t *b2,
+                    len_t II, len_t JJ, len_t KK, int ipl);
+void orc3_planes_relax(orc_planes *p, const real_t *so, real_t *x, const real_t *b, int updown);
 int orc_ml_nlevels(const orc_ml *ml);
 void orc_ml_level_dims(const orc_ml *ml, int lvl, len_t *nx, len_t *ny, len_t *nz);
 /* raw access to a level's arrays for parity tests: what = "A","P","SOR0","SOR1","ABD" */

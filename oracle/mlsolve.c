@@ -21,10 +21,12 @@ typedef struct {
 	real_t *P;            /* interpolation from this level to the finer one (levels >= 1) */
 	real_t *x, *b, *res;  /* level 0: x and b are the caller's */
 	real_t *SOR0, *SOR1;
+	orc_planes *pl[3];    /* plane relaxation: xy, xz, yz solvers of this level (relax_planes.h:164-246) */
 } orc_level;
 
 struct orc_ml {
 	int nd, nlev, relax, nrelax_pre, nrelax_post, cycle;
+	int pcfg[5]; real_t ptol; int has_pcfg; /* "plane-config" (src/kernel_params.cc:72-78) */
 	int ibc;              /* 0 Dirichlet; 1 per_y, 2 per_x, 3 per_xy; 3D also 5 per_z, 6 per_xz, 7 per_yz, 8 per_xyz
 	                       * (BMG_get_bc.f90:13-20) */
 	orc_level *lv;
@@ -86,9 +88,19 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
                          int relax, int nrelax_pre, int nrelax_post, int min_coarse,
                          int num_levels, int ibc)
 {
+	return orc_ml_create_ex(nd, nx, ny, nz, nstencil, so, relax, nrelax_pre, nrelax_post, min_coarse, num_levels, ibc, NULL, 0.0);
+}
+
+/* relax = ORC_RELAX_PLANE_* (3D): plane_cfg / plane_tol = the 2D solvers' configuration (orc3_planes_create) */
+orc_ml *orc_ml_create_ex(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                         int relax, int nrelax_pre, int nrelax_post, int min_coarse,
+                         int num_levels, int ibc, const int *plane_cfg, real_t plane_tol)
+{
+	if (relax >= ORC_RELAX_PLANE_XY && (nd != 3 || ibc != 0)) return NULL;
 	if (ibc != 0 && nd == 3 && !(ibc == 1 || ibc == 2 || ibc == 3 || (ibc >= 5 && ibc <= 8))) return NULL;
 	orc_ml *ml = (orc_ml *)calloc(1, sizeof(orc_ml));
 	ml->ibc = ibc;
+	if (plane_cfg) { memcpy(ml->pcfg, plane_cfg, sizeof(ml->pcfg)); ml->ptol = plane_tol; ml->has_pcfg = 1; }
 	ml->nd = nd; ml->relax = relax;
 	ml->nrelax_pre = nrelax_pre; ml->nrelax_post = nrelax_post;
 	int nlev = compute_num_levels(nd, nx, ny, nz, min_coarse);
@@ -146,7 +158,12 @@ orc_ml *orc_ml_create_bc(int nd, len_t nx, len_t ny, len_t nz, int nstencil, con
 		} else {
 			orc3_setup_interp(F->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd);
 			orc3_galerkin(F->A, K->A, K->P, F->II, F->JJ, F->KK, K->II, K->JJ, K->KK, ifd);
-			orc3_setup_recip(F->A, F->SOR0, F->II, F->JJ, F->KK);
+			if (relax >= ORC_RELAX_PLANE_XY) { /* multilevel.h:149-159 */
+				for (int d = 0; d < 3; d++)
+					if (relax == ORC_RELAX_PLANE_XYZ || relax == ORC_RELAX_PLANE_XY + d)
+						F->pl[d] = orc3_planes_create(d, F->A, F->II, F->JJ, F->KK, F->nst, ml->has_pcfg ? ml->pcfg : NULL, ml->ptol);
+			} else
+				orc3_setup_recip(F->A, F->SOR0, F->II, F->JJ, F->KK);
 		}
 	}
 	/* setup_cg_solve (multilevel.h:95-103) */
@@ -163,6 +180,7 @@ void orc_ml_destroy(orc_ml *ml)
 	for (int l = 0; l < ml->nlev; l++) {
 		orc_level *L = &ml->lv[l];
 		free(L->A); free(L->P); free(L->res); free(L->SOR0); free(L->SOR1);
+		for (int d = 0; d < 3; d++) orc3_planes_destroy(L->pl[d]);
 		if (l > 0) { free(L->x); free(L->b); }
 	}
 	free(ml->lv); free(ml->ABD); free(ml->bbd); free(ml->work); free(ml);
@@ -199,6 +217,14 @@ static void smooth(const orc_ml *ml, orc_level *L, real_t *x, const real_t *b, i
 	for (int it = 0; it < n; it++) {
 		if (ml->nd == 3 && ml->ibc) {
 			orc3_relax_gs_per(L->A, b, x, L->SOR0, L->II, L->JJ, L->KK, L->nst == 4, updown, ml->ibc);
+			continue;
+		}
+		if (ml->nd == 3 && ml->relax >= ORC_RELAX_PLANE_XY) { /* multilevel.h:179-189, :208-218 */
+			static const int down[3] = { 0, 2, 1 }, up[3] = { 1, 2, 0 }; /* xy, yz, xz / xz, yz, xy */
+			for (int t = 0; t < 3; t++) {
+				const int d = updown == BMG_DOWN ? down[t] : up[t];
+				if (L->pl[d]) orc3_planes_relax(L->pl[d], L->A, x, b, updown);
+			}
 			continue;
 		}
 		if (ml->nd == 3) {

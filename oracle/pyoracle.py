@@ -21,7 +21,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 P = C.POINTER(C.c_double)
 u = C.c_uint
 DOWN, UP = 0, 1
-RELAX = {"point": 0, "line-x": 1, "line-y": 2, "line-xy": 3}
+RELAX = {"point": 0, "line-x": 1, "line-y": 2, "line-xy": 3, "plane-xy": 4, "plane-xz": 5, "plane-yz": 6, "plane-xyz": 7}
+PLANE_DIR = {"xy": 0, "xz": 1, "yz": 2}
+
+
+def plane_cfg(plane):
+    """plane = dict(relax=, nrelax_pre=, nrelax_post=, max_iter=, min_coarse=, tol=) or None (the reference's default
+    plane configuration, src/kernel_params.cc:72-78) -> (int[5] or None, tol)"""
+    if plane is None:
+        return None, 0.0
+    cfg = (C.c_int * 5)(RELAX[plane.get("relax", "line-xy")], plane.get("nrelax_pre", 2), plane.get("nrelax_post", 1),
+                        plane.get("max_iter", 1), plane.get("min_coarse", 3))
+    return cfg, float(plane.get("tol", 1e-8))
 
 
 def _p(a):
@@ -248,7 +259,22 @@ class Oracle:
         return self.L.orc_l2_norm3(_p(v), u(v.shape[2]), u(v.shape[1]), u(v.shape[0]))
 
     # ---------------- multilevel ----------------
-    def ml_create(self, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, num_levels=-1, cycle="v", ibc=0):
+    # ---------------- plane relaxation ----------------
+    def plane_rhs3(self, so, x, b, b2, d, ipl):
+        nst, KK, JJ, II = so.shape
+        self.L.orc3_plane_rhs(PLANE_DIR[d], nst, _p(so), _p(x), _p(b), _p(b2), u(II), u(JJ), u(KK), ipl)
+
+    def relax_planes3(self, so, x, b, d, updown, plane=None):
+        """kman->setup<plane_relax<d>>(so); kman->run<plane_relax<d>>(so, x, b, updown)"""
+        nst, KK, JJ, II = so.shape
+        cfg, tol = plane_cfg(plane)
+        self.L.orc3_planes_create.restype = C.c_void_p
+        h = C.c_void_p(self.L.orc3_planes_create(PLANE_DIR[d], _p(so), u(II), u(JJ), u(KK), nst, cfg, C.c_double(tol)))
+        self.L.orc3_planes_relax(h, _p(so), _p(x), _p(b), updown)
+        self.L.orc3_planes_destroy(h)
+
+    def ml_create(self, so, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3, num_levels=-1, cycle="v", ibc=0,
+                  plane=None):
         nd = so.ndim - 1
         if nd == 2:
             nst, JJ, II = so.shape
@@ -256,9 +282,10 @@ class Oracle:
         else:
             nst, KK, JJ, II = so.shape
             nx, ny, nz = II - 2, JJ - 2, KK - 2
-        self.L.orc_ml_create_bc.restype = C.c_void_p
-        h = self.L.orc_ml_create_bc(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
-                                    nrelax_pre, nrelax_post, min_coarse, num_levels, ibc)
+        self.L.orc_ml_create_ex.restype = C.c_void_p
+        cfg, tol = plane_cfg(plane)
+        h = self.L.orc_ml_create_ex(nd, u(nx), u(ny), u(nz), nst, _p(so), RELAX[relax],
+                                    nrelax_pre, nrelax_post, min_coarse, num_levels, ibc, cfg, C.c_double(tol))
         if not h:
             raise ValueError("unknown boundary code %r" % (ibc,))
         m = MLHandle(self, h, nd)
