@@ -30,7 +30,8 @@ lib = C.CDLL(LIBPATH)
 P = C.POINTER(C.c_double)
 u = C.c_uint
 DOWN, UP = 0, 1
-RELAX = {"point": 0, "line-x": 1, "line-y": 2, "line-xy": 3}
+RELAX = {"point": 0, "line-x": 1, "line-y": 2, "line-xy": 3, "plane-xy": 4, "plane-xz": 5, "plane-yz": 6, "plane-xyz": 7}
+PLANE_DIR = {"xy": 0, "xz": 1, "yz": 2}
 
 lib.cedar_amd_malloc.restype = C.c_void_p
 lib.cedar_amd_malloc.argtypes = [C.c_size_t]
@@ -49,7 +50,20 @@ lib.cedar_amd_set_stream.argtypes = [C.c_void_p]
 class Settings(C.Structure):
     _fields_ = [("relaxation", C.c_int), ("nrelax_pre", C.c_int), ("nrelax_post", C.c_int),
                 ("num_levels", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double),
-                ("min_coarse", C.c_int), ("cycle", C.c_int), ("ibc", C.c_int)]
+                ("min_coarse", C.c_int), ("cycle", C.c_int), ("ibc", C.c_int),
+                ("plane_relaxation", C.c_int), ("plane_nrelax_pre", C.c_int), ("plane_nrelax_post", C.c_int),
+                ("plane_max_iter", C.c_int), ("plane_min_coarse", C.c_int), ("plane_tol", C.c_double)]
+
+
+def plane_settings(st, plane):
+    """fill the "plane-config" part of a Settings from plane = dict(relax=, nrelax_pre=, nrelax_post=, max_iter=,
+    min_coarse=, tol=) or None (the reference's default: line-xy, one cycle per plane)"""
+    plane = plane or {}
+    st.plane_relaxation = RELAX[plane.get("relax", "line-xy")]
+    st.plane_nrelax_pre, st.plane_nrelax_post = plane.get("nrelax_pre", 2), plane.get("nrelax_post", 1)
+    st.plane_max_iter, st.plane_min_coarse = plane.get("max_iter", 1), plane.get("min_coarse", 3)
+    st.plane_tol = float(plane.get("tol", 1e-8))
+    return st
 
 
 def device_count():
@@ -246,6 +260,24 @@ class Kernels:
         bbd = np.zeros(n2)
         lib.BMG3_SymStd_SOLVE_cg(_p(q), _p(qf), u(II), u(JJ), u(KK), _p(abd), _p(bbd), u(n1), u(n2), ibc)
 
+    def relax_planes3(self, so, x, b, d, updown, plane=None):
+        """kman->setup<plane_relax<d>>(so); kman->run<plane_relax<d>>(so, x, b, updown) (cedar_amd_planes_*)"""
+        nst, KK, JJ, II = so.shape
+        st = None
+        if plane is not None:
+            st = Settings()
+            lib.cedar_amd_default_settings(C.byref(st))
+            st.relaxation = RELAX[plane.get("relax", "line-xy")]
+            st.nrelax_pre, st.nrelax_post = plane.get("nrelax_pre", 2), plane.get("nrelax_post", 1)
+            st.max_iter, st.min_coarse, st.tol = plane.get("max_iter", 1), plane.get("min_coarse", 3), float(plane.get("tol", 1e-8))
+        lib.cedar_amd_planes_create.restype = C.c_void_p
+        h = lib.cedar_amd_planes_create(PLANE_DIR[d], u(II - 2), u(JJ - 2), u(KK - 2), nst, _p(so), C.byref(st) if st else None)
+        if not h:
+            raise RuntimeError("cedar_amd_planes_create failed")
+        h = C.c_void_p(h)
+        lib.cedar_amd_planes_run(h, _p(so), _p(x), _p(b), updown)
+        lib.cedar_amd_planes_destroy(h)
+
     def l2(self, v):
         return l2norm(v)
 
@@ -302,7 +334,7 @@ class Solver:
     """cedar::cdr2::solver / cdr3::solver on the device (include/cedar_amd.h, handle API)."""
 
     def __init__(self, so, relax="point", nrelax_pre=2, nrelax_post=1, num_levels=-1,
-                 max_iter=10, tol=1e-8, min_coarse=3, share_operator=False, cycle="v", ibc=0):
+                 max_iter=10, tol=1e-8, min_coarse=3, share_operator=False, cycle="v", ibc=0, plane=None):
         shp = so.shape
         self.nd = len(shp) - 1
         nst = shp[0]
@@ -311,6 +343,7 @@ class Solver:
         self.shape = tuple(shp[1:])
         st = Settings(RELAX[relax], nrelax_pre, nrelax_post, num_levels, max_iter, tol, min_coarse,
                       {"v": 0, "f": 1}[cycle], ibc)
+        plane_settings(st, plane)
         self.max_iter = max_iter
         self._so = so if share_operator else None  # keep the shared operator alive
         self.h = lib.cedar_amd_solver_create(self.nd, nx, ny, nz, nst, _vp(so), int(share_operator), C.byref(st))

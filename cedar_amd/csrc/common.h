@@ -148,6 +148,11 @@ void galerkin3_per(const real_t *so, real_t *soc, const real_t *ci, int IIF, int
 void setup_cg3_per(const real_t *so, int II, int JJ, int KK, real_t *abd, int nabd1, int ipn, int *info, hipStream_t st);
 void solve_cg3_per(real_t *q, const real_t *qf, int II, int JJ, int KK, const real_t *abd, real_t *bbd, int nabd1, int ipn,
                    hipStream_t st);
+// plane relaxation, the 3D side (planes.hip); dir 0 xy, 1 xz, 2 yz; stacked 2D arrays, slot q = plane beg + 2q
+void plane_operator(int dir, int nst, const real_t *so, real_t *so2, int II, int JJ, int KK, hipStream_t st);
+void plane_gather(int dir, int nst, const real_t *so, const real_t *x, const real_t *b, real_t *x2s, real_t *b2s,
+                  int II, int JJ, int KK, int beg, int nslots, hipStream_t st);
+void plane_scatter(int dir, const real_t *x2s, real_t *x, int II, int JJ, int KK, int beg, int nslots, hipStream_t st);
 // qf = A q (operator application with Cedar's sign convention), residual.hip
 void matvec2(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int nstncl, hipStream_t st);
 void matvec3(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int KK, int nstncl, hipStream_t st);

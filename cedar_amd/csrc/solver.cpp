@@ -41,6 +41,23 @@ struct Level {
 	real_t *PFx = nullptr, *PFy = nullptr;
 	// 3D 27-point: row-interleaved solve copy of A and 1/diag (common.h Op3) read by relax and residual
 	real_t *Ailv = nullptr;
+	// the set-up products (A, P, SOR, At, PF*) belong to another solver of the same operator (plane relaxation:
+	// every plane solver of a direction is built from the same 2D operator); this level owns only its vectors
+	bool shared = false;
+	// plane relaxation (3D): the plane solvers of this level, one set per direction in use (xy, xz, yz)
+	struct PlaneSet *pl[3] = {nullptr, nullptr, nullptr};
+};
+
+// include/cedar/3d/relax_planes.h:164-246.  The reference keeps one 2D solver per plane; copy_coeff gives all of
+// them the same operator (planes.hip), so one hierarchy is set up and the others share its set-up products.  Planes
+// of one colour are independent: instance q serves the planes 2q+1 and 2q+2 (one of each colour) on fixed 2D vectors
+// (slot q of x2s / b2s), so its V-cycle is captured into a hipGraph once and replayed; the replays of a colour are
+// spread over a few streams.
+struct PlaneSet {
+	int dir = 0, np = 0, I2 = 0, J2 = 0;
+	size_t P2 = 0;
+	real_t *so2 = nullptr, *x2s = nullptr, *b2s = nullptr;
+	std::vector<cedar_amd_solver *> inst;
 };
 
 real_t *dalloc_raw(size_t n) // not cleared: the caller writes every element
@@ -74,6 +91,11 @@ struct cedar_amd_solver {
 	const real_t *gx = nullptr, *gb = nullptr;
 	hipStream_t gstream = nullptr;
 	bool use_graph = true;
+	bool shared_abd = false; // ABD belongs to the solver this one was cloned from
+	// plane relaxation: side streams and their fork / join events
+	std::vector<hipStream_t> pstreams;
+	std::vector<hipEvent_t> pevents;
+	hipEvent_t pfork = nullptr;
 };
 
 namespace {
@@ -168,9 +190,123 @@ void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int 
 	relax_lines_yt(L.At, L.bt, x, L.xt, sor, L.II, L.JJ, L.nst, updown, st, L.PFy);
 }
 
+// ------------------------------------------------------------------ plane relaxation
+void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st);
+double l2_dev(cedar_amd_solver *s, const Level &L, const real_t *v);
+void residual(const cedar_amd_solver *s, const Level &L, const real_t *x, const real_t *b, real_t *r, hipStream_t st);
+
+// a solver on the same operator as `proto` that shares its set-up products and owns only its vectors
+cedar_amd_solver *clone_vectors(const cedar_amd_solver *proto)
+{
+	cedar_amd_solver *c = new cedar_amd_solver;
+	c->nd = proto->nd; c->st = proto->st; c->use_graph = proto->use_graph;
+	c->lv = proto->lv; // pointers to the shared products; the vectors are replaced below
+	for (size_t l = 0; l < c->lv.size(); l++) {
+		Level &L = c->lv[l];
+		L.shared = true; L.ownA = false;
+		L.res = dalloc(L.npts);
+		if (L.yscr) L.yscr = dalloc(ylines_scratch_doubles(L.II, L.JJ));
+		if (L.bt) { L.bt = dalloc(L.npts); L.xt = dalloc(L.npts); }
+		L.bt_fresh = false;
+		if (l > 0) { L.x = dalloc(L.npts); L.b = dalloc(L.npts); }
+	}
+	c->ABD = proto->ABD; c->shared_abd = true;
+	c->nabd1 = proto->nabd1; c->nabd2 = proto->nabd2;
+	c->bbd = dalloc(c->nabd2);
+	c->red = dalloc(4100);
+	CEDAR_HIP_CHECK(hipMalloc((void **)&c->dinfo, 64));
+	return c;
+}
+
+// kman->setup<plane_relax<dir>>(so): the 2D operator, one full 2D set-up, vector-only clones for the other instances
+PlaneSet *planes_setup(int dir, const real_t *so3, int II, int JJ, int KK, int nst, const cedar_amd_settings &pst, hipStream_t st)
+{
+	PlaneSet *ps = new PlaneSet;
+	ps->dir = dir;
+	ps->I2 = dir == 2 ? JJ : II;
+	ps->J2 = dir == 0 ? JJ : KK;
+	ps->np = (dir == 0 ? KK : dir == 1 ? JJ : II) - 2;
+	ps->P2 = (size_t)ps->I2 * ps->J2;
+	const int nst2 = nst == 14 ? 5 : 3, ninst = (ps->np + 1) / 2;
+	ps->so2 = dalloc_raw(ps->P2 * nst2);
+	plane_operator(dir, nst, so3, ps->so2, II, JJ, KK, st);
+	ps->x2s = dalloc(ps->P2 * ninst);
+	ps->b2s = dalloc(ps->P2 * ninst); // ghost entries stay zero: plane_gather writes interiors only
+	cedar_amd_solver *first = cedar_amd_solver_create(2, ps->I2 - 2, ps->J2 - 2, 1, nst2, ps->so2, 1, &pst);
+	if (!first) {
+		(void)hipFree(ps->so2); (void)hipFree(ps->x2s); (void)hipFree(ps->b2s);
+		delete ps;
+		return nullptr;
+	}
+	ps->inst.push_back(first);
+	for (int q = 1; q < ninst; q++) ps->inst.push_back(clone_vectors(first));
+	return ps;
+}
+
+void planes_destroy(PlaneSet *ps)
+{
+	if (!ps) return;
+	for (size_t q = ps->inst.size(); q-- > 0;) cedar_amd_solver_destroy(ps->inst[q]); // clones before the owner of the products
+	(void)hipFree(ps->so2); (void)hipFree(ps->x2s); (void)hipFree(ps->b2s);
+	delete ps;
+}
+
+// relax_planes (relax_planes.h:36-72): DOWN = the odd planes (1, 3, ..), then the even ones; UP = even, then odd.
+// Per colour: gather all its planes and right-hand sides (one launch), one 2D solve per plane, scatter (one launch).
+// Plane configuration max-iter 1 (the reference's default): the solve is one V-cycle whatever the norms are, replayed
+// from the instance's graph on a side stream; otherwise multilevel::solve's loop with its host-side tolerance test.
+void planes_relax(cedar_amd_solver *s3, PlaneSet &ps, const Level &L, real_t *x, const real_t *b, int updown, hipStream_t st)
+{
+	const int order[2] = {updown == BMG_DOWN ? 1 : 2, updown == BMG_DOWN ? 2 : 1};
+	for (int c = 0; c < 2; c++) {
+		const int beg = order[c];
+		const int n = beg > ps.np ? 0 : (ps.np - beg) / 2 + 1;
+		if (n == 0) continue;
+		plane_gather(ps.dir, L.nst, L.A, x, b, ps.x2s, ps.b2s, L.II, L.JJ, L.KK, beg, n, st);
+		const int maxit = ps.inst[0]->st.max_iter;
+		if (maxit == 1) {
+			const int S = (int)s3->pstreams.size() < n ? (int)s3->pstreams.size() : n;
+			if (S <= 1) {
+				for (int q = 0; q < n; q++) cycle_on(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q, st);
+			} else {
+				CEDAR_HIP_CHECK(hipEventRecord(s3->pfork, st));
+				for (int t = 0; t < S; t++) CEDAR_HIP_CHECK(hipStreamWaitEvent(s3->pstreams[t], s3->pfork, 0));
+				for (int q = 0; q < n; q++) cycle_on(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q, s3->pstreams[q % S]);
+				for (int t = 0; t < S; t++) {
+					CEDAR_HIP_CHECK(hipEventRecord(s3->pevents[t], s3->pstreams[t]));
+					CEDAR_HIP_CHECK(hipStreamWaitEvent(st, s3->pevents[t], 0));
+				}
+			}
+		} else {
+			for (int q = 0; q < n; q++) { // multilevel.h:277-298
+				cedar_amd_solver *p = ps.inst[q];
+				Level &L2 = p->lv[0];
+				real_t *x2 = ps.x2s + ps.P2 * q;
+				const real_t *b2 = ps.b2s + ps.P2 * q;
+				residual(p, L2, x2, b2, L2.res, st);
+				const double res0 = l2_dev(p, L2, L2.res);
+				for (int it = 0; it < maxit; it++) {
+					cycle_on(p, x2, b2, st);
+					residual(p, L2, x2, b2, L2.res, st);
+					if (l2_dev(p, L2, L2.res) / res0 < p->st.tol) break;
+				}
+			}
+		}
+		plane_scatter(ps.dir, ps.x2s, x, L.II, L.JJ, L.KK, beg, n, st);
+	}
+}
+
 void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *b, int updown, int n, hipStream_t st)
 {
 	for (int it = 0; it < n; it++) {
+		if (s->nd == 3 && s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY) { // multilevel.h:179-189, :208-218
+			static const int down[3] = {0, 2, 1}, up[3] = {1, 2, 0}; // xy, yz, xz on the way down; xz, yz, xy on the way up
+			for (int t = 0; t < 3; t++) {
+				const int d = updown == BMG_DOWN ? down[t] : up[t];
+				if (L.pl[d]) planes_relax(const_cast<cedar_amd_solver *>(s), *L.pl[d], L, x, b, updown, st);
+			}
+			continue;
+		}
 		if (s->nd == 3 && s->st.ibc) {
 			relax3_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, s->st.ibc, st);
 			continue;
@@ -258,9 +394,11 @@ void cycle_launch(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t s
 }
 
 // run one V-cycle on device pointers: graph replay when possible
-void cycle_dev(cedar_amd_solver *s, real_t *x, const real_t *b)
+void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st);
+void cycle_dev(cedar_amd_solver *s, real_t *x, const real_t *b) { cycle_on(s, x, b, current_stream()); }
+
+void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 {
-	hipStream_t st = current_stream();
 	if (!s->use_graph) {
 		cycle_launch(s, x, b, st);
 		return;
@@ -270,7 +408,11 @@ void cycle_dev(cedar_amd_solver *s, real_t *x, const real_t *b)
 		s->gexec = nullptr;
 	}
 	if (!s->gexec) {
-		if (!s->gstream) CEDAR_HIP_CHECK(hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking));
+		// one capture stream for the process: captures are recorded synchronously (thread-local mode), and plane
+		// relaxation keeps hundreds of small solvers whose graphs are all recorded through here
+		static hipStream_t capture_stream = nullptr;
+		if (!capture_stream) CEDAR_HIP_CHECK(hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking));
+		s->gstream = capture_stream;
 		// one eager cycle first is NOT wanted (it would change x); capture records without executing
 		CEDAR_HIP_CHECK(hipStreamSynchronize(st));
 		hipGraph_t g = nullptr;
@@ -308,6 +450,12 @@ void cedar_amd_default_settings(cedar_amd_settings *s)
 	s->min_coarse = 3;
 	s->cycle = 0;
 	s->ibc = 0;
+	s->plane_relaxation = CEDAR_AMD_RELAX_LINE_XY; // src/kernel_params.cc:72-78
+	s->plane_nrelax_pre = 2;
+	s->plane_nrelax_post = 1;
+	s->plane_max_iter = 1;
+	s->plane_min_coarse = 3;
+	s->plane_tol = 1e-8;
 }
 
 cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil,
@@ -319,10 +467,30 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	s->nd = nd;
 	if (settings) s->st = *settings;
 	else cedar_amd_default_settings(&s->st);
-	if (nd == 3 && s->st.relaxation != CEDAR_AMD_RELAX_POINT) {
-		char msg[] = "cedar_amd_solver_create: 3D supports point relaxation only (plane relaxation is out of scope)";
+	const bool planes = s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY && s->st.relaxation <= CEDAR_AMD_RELAX_PLANE_XYZ;
+	if ((nd == 3 && s->st.relaxation != CEDAR_AMD_RELAX_POINT && !planes) || (nd == 2 && planes)
+	    || (planes && (s->st.ibc != 0 || s->st.plane_relaxation >= CEDAR_AMD_RELAX_PLANE_XY))) {
+		char msg[] = "cedar_amd_solver_create: relaxation must be point / line-x / line-y / line-xy in 2D and point or "
+		             "plane-xy / -xz / -yz / -xyz in 3D (planes: Dirichlet boundaries, a 2D relaxation in the plane "
+		             "configuration); point relaxation is used";
 		print_error(msg);
 		s->st.relaxation = CEDAR_AMD_RELAX_POINT;
+	}
+	if (s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY) {
+		// the plane solves of a colour run on side streams and replay graphs of their own: the 3D cycle is launched
+		// eagerly (capturing it would nest graph launches)
+		s->use_graph = false;
+		const char *es = getenv("CEDAR_AMD_PLANE_STREAMS");
+		int S = es ? atoi(es) : 8;
+		if (S < 1) S = 1;
+		if (S > 64) S = 64;
+		s->pstreams.resize(S);
+		s->pevents.resize(S);
+		for (int t = 0; t < S; t++) {
+			CEDAR_HIP_CHECK(hipStreamCreateWithFlags(&s->pstreams[t], hipStreamNonBlocking));
+			CEDAR_HIP_CHECK(hipEventCreateWithFlags(&s->pevents[t], hipEventDisableTiming));
+		}
+		CEDAR_HIP_CHECK(hipEventCreateWithFlags(&s->pfork, hipEventDisableTiming));
 	}
 	if (s->st.ibc != 0) {
 		// periodic boundary conditions: V-cycle.  2D: ibc 1..3, point relaxation keeps a row in the default LDS
@@ -339,7 +507,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 			return nullptr;
 		}
 	}
-	if (const char *e = getenv("CEDAR_AMD_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+	if (const char *e = getenv("CEDAR_AMD_NO_GRAPH")) s->use_graph = s->use_graph && !(e[0] == '1');
 	int nlev = compute_num_levels(nd, nx, ny, nz, s->st.min_coarse);
 	if (s->st.num_levels > 0) {
 		if (s->st.num_levels > nlev) {
@@ -437,6 +605,17 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 				setup_interp3(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
 				galerkin3(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, ifd, st);
 			}
+			if (s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY) { // multilevel.h:149-159
+				cedar_amd_settings pst;
+				cedar_amd_default_settings(&pst);
+				pst.relaxation = s->st.plane_relaxation; pst.nrelax_pre = s->st.plane_nrelax_pre;
+				pst.nrelax_post = s->st.plane_nrelax_post; pst.max_iter = s->st.plane_max_iter;
+				pst.tol = s->st.plane_tol; pst.min_coarse = s->st.plane_min_coarse;
+				for (int d = 0; d < 3; d++)
+					if (s->st.relaxation == CEDAR_AMD_RELAX_PLANE_XYZ || s->st.relaxation == CEDAR_AMD_RELAX_PLANE_XY + d)
+						F.pl[d] = planes_setup(d, F.A, F.II, F.JJ, F.KK, F.nst, pst, st);
+				continue;
+			}
 			setup_recip(F.A, F.SOR0 + F.npts, F.II, F.JJ, F.KK, st);
 			if (F.nst == 14 && !s->st.ibc && ilv_wanted(F)) {
 				F.Ailv = dalloc_raw(ilv_doubles(F.II, F.JJ, F.KK));
@@ -464,16 +643,22 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 	if (!s) return;
 	CEDAR_HIP_CHECK(hipDeviceSynchronize());
 	if (s->gexec) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
-	if (s->gstream) CEDAR_HIP_CHECK(hipStreamDestroy(s->gstream));
 	for (size_t l = 0; l < s->lv.size(); l++) {
 		Level &L = s->lv[l];
+		for (int d = 0; d < 3; d++) planes_destroy(L.pl[d]);
 		if (L.ownA) (void)hipFree(L.A);
-		(void)hipFree(L.P); (void)hipFree(L.res); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.yscr);
-		(void)hipFree(L.At); (void)hipFree(L.bt); (void)hipFree(L.xt); (void)hipFree(L.Ailv);
-		(void)hipFree(L.PFx); (void)hipFree(L.PFy);
+		if (!L.shared) {
+			(void)hipFree(L.P); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.At); (void)hipFree(L.Ailv);
+			(void)hipFree(L.PFx); (void)hipFree(L.PFy);
+		}
+		(void)hipFree(L.res); (void)hipFree(L.yscr); (void)hipFree(L.bt); (void)hipFree(L.xt);
 		if (l > 0) { (void)hipFree(L.x); (void)hipFree(L.b); }
 	}
-	(void)hipFree(s->ABD); (void)hipFree(s->bbd); (void)hipFree(s->red); (void)hipFree(s->dinfo);
+	if (!s->shared_abd) (void)hipFree(s->ABD);
+	(void)hipFree(s->bbd); (void)hipFree(s->red); (void)hipFree(s->dinfo);
+	for (auto t : s->pstreams) (void)hipStreamDestroy(t);
+	for (auto e : s->pevents) (void)hipEventDestroy(e);
+	if (s->pfork) (void)hipEventDestroy(s->pfork);
 	delete s;
 }
 
@@ -547,6 +732,77 @@ int cedar_amd_solver_solve(cedar_amd_solver *s, const real_t *b, real_t *x, real
 	}
 	launch_check("cedar_amd_solver_solve");
 	return it;
+}
+
+// ---- plane relaxation as a kernel of its own: kernels::plane_relax<stypes, rdir>::setup / run
+// (include/cedar/kernels/plane_relax.h:10-33, include/cedar/3d/relax_planes.h:164-246)
+struct cedar_amd_planes {
+	cedar_amd_solver *host = nullptr; // carries the side streams
+	PlaneSet *ps = nullptr;
+	Level L;                          // extents and stencil of the 3D operator
+};
+
+cedar_amd_planes *cedar_amd_planes_create(int dir, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                                          const cedar_amd_settings *plane_settings)
+{
+	if (dir < 0 || dir > 2 || (nstencil != 4 && nstencil != 14)) {
+		char msg[] = "cedar_amd_planes_create: dir must be 0 (xy), 1 (xz) or 2 (yz), nstencil 4 or 14";
+		print_error(msg);
+		return nullptr;
+	}
+	hipStream_t st = current_stream();
+	cedar_amd_settings pst;
+	if (plane_settings) pst = *plane_settings;
+	else { // the reference's default plane configuration, src/kernel_params.cc:72-78
+		cedar_amd_default_settings(&pst);
+		pst.relaxation = CEDAR_AMD_RELAX_LINE_XY;
+		pst.max_iter = 1;
+	}
+	cedar_amd_planes *p = new cedar_amd_planes;
+	p->L.nx = (int)nx; p->L.ny = (int)ny; p->L.nz = (int)nz;
+	p->L.II = (int)nx + 2; p->L.JJ = (int)ny + 2; p->L.KK = (int)nz + 2;
+	p->L.nst = nstencil;
+	p->L.npts = (size_t)p->L.II * p->L.JJ * p->L.KK;
+	p->host = new cedar_amd_solver;
+	p->host->nd = 3;
+	const char *es = getenv("CEDAR_AMD_PLANE_STREAMS");
+	int S = es ? atoi(es) : 8;
+	S = S < 1 ? 1 : S > 64 ? 64 : S;
+	p->host->pstreams.resize(S);
+	p->host->pevents.resize(S);
+	for (int t = 0; t < S; t++) {
+		CEDAR_HIP_CHECK(hipStreamCreateWithFlags(&p->host->pstreams[t], hipStreamNonBlocking));
+		CEDAR_HIP_CHECK(hipEventCreateWithFlags(&p->host->pevents[t], hipEventDisableTiming));
+	}
+	CEDAR_HIP_CHECK(hipEventCreateWithFlags(&p->host->pfork, hipEventDisableTiming));
+	{
+		Staged sso(so, p->L.npts * nstencil, true, false);
+		p->ps = planes_setup(dir, sso.get(), p->L.II, p->L.JJ, p->L.KK, nstencil, pst, st);
+	}
+	if (!p->ps) {
+		cedar_amd_solver_destroy(p->host);
+		delete p;
+		return nullptr;
+	}
+	return p;
+}
+
+void cedar_amd_planes_run(cedar_amd_planes *p, const real_t *so, real_t *x, const real_t *b, int updown)
+{
+	if (null_handle(p, "cedar_amd_planes_run")) return;
+	Staged sso(so, p->L.npts * p->L.nst, true, false), sx(x, p->L.npts, true, true), sb(b, p->L.npts, true, false);
+	Level L = p->L;
+	L.A = sso.get();
+	planes_relax(p->host, *p->ps, L, sx.get(), sb.get(), updown, current_stream());
+}
+
+void cedar_amd_planes_destroy(cedar_amd_planes *p)
+{
+	if (!p) return;
+	CEDAR_HIP_CHECK(hipDeviceSynchronize());
+	planes_destroy(p->ps);
+	cedar_amd_solver_destroy(p->host);
+	delete p;
 }
 
 float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n)

@@ -78,6 +78,7 @@ public:
 			km->template setup<kernels::line_relax<stypes, relax_dir::x>>(level.A, level.SOR[0]);
 			km->template setup<kernels::line_relax<stypes, relax_dir::y>>(level.A, level.SOR[1]);
 			break;
+		default: log::error << "cdr2::solver: plane relaxation is a 3D smoother" << std::endl;
 		}
 	}
 	// multilevel.h:170-222: pre = DOWN (line-xy: x then y), post = UP (y then x)
@@ -102,6 +103,7 @@ public:
 					km->template run<lx>(A, x, b, level.SOR[0], level.res, dir);
 				}
 				break;
+			default: break;
 			}
 		}
 	}

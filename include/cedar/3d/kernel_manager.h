@@ -4,10 +4,13 @@
 // binding classes call -- served by libcedar_amd.so.
 #ifndef CEDAR_3D_KERNEL_MANAGER_H
 #define CEDAR_3D_KERNEL_MANAGER_H
+#include <map>
 #include <type_traits>
+#include <utility>
 #include <cedar/kernel_manager.h>
 #include <cedar/kernels/coarsen_op.h>
 #include <cedar/kernels/interp_add.h>
+#include <cedar/kernels/plane_relax.h>
 #include <cedar/kernels/point_relax.h>
 #include <cedar/kernels/residual.h>
 #include <cedar/kernels/restrict.h>
@@ -160,11 +163,58 @@ public:
 	}
 };
 
+// the 2D solvers' settings from a configuration block ("plane-config", src/kernel_params.cc:72-78)
+inline cedar_amd_settings plane_settings(config & pc)
+{
+	cedar_amd_settings pst;
+	cedar_amd_default_settings(&pst);
+	ml_settings ms;
+	ms.init(pc);
+	pst.relaxation = static_cast<int>(ms.relaxation);
+	pst.nrelax_pre = ms.nrelax_pre; pst.nrelax_post = ms.nrelax_post;
+	pst.max_iter = ms.maxiter; pst.tol = ms.tol; pst.min_coarse = ms.min_coarse;
+	return pst;
+}
+
+// include/cedar/3d/relax_planes.h:164-246: plane relaxation of one direction.  setup() is called once per level
+// (multilevel.h:149-159); like the reference the sets of the 27-point levels are found again by the level's x extent
+// (level_map) and the seven-point fine level keeps its own.
+template <relax_dir rdir> class planes : public kernels::plane_relax<stypes, rdir> {
+public:
+	~planes() { for (auto & kv : sets) cedar_amd_planes_destroy(kv.second); }
+	void setup(const stencil_op<seven_pt> & so) override { this->setup_impl(so); }
+	void setup(const stencil_op<xxvii_pt> & so) override { this->setup_impl(so); }
+	void run(const stencil_op<seven_pt> & so, grid_func & x, const grid_func & b, cycle::Dir cycle_dir) override { this->run_impl(so, x, b, cycle_dir); }
+	void run(const stencil_op<xxvii_pt> & so, grid_func & x, const grid_func & b, cycle::Dir cycle_dir) override { this->run_impl(so, x, b, cycle_dir); }
+	template <class sten> void setup_impl(const stencil_op<sten> & so)
+	{
+		auto & sod = const_cast<stencil_op<sten> &>(so);
+		cedar_amd_settings pst = plane_settings(*this->params->plane_config);
+		auto key = std::make_pair(std::is_same<sten, seven_pt>::value, so.shape(0));
+		if (sets.count(key)) cedar_amd_planes_destroy(sets[key]);
+		sets[key] = cedar_amd_planes_create(dir(), so.shape(0), so.shape(1), so.shape(2), stencil_ndirs<sten>::value, sod.data(), &pst);
+	}
+	template <class sten> void run_impl(const stencil_op<sten> & so, grid_func & x, const grid_func & b, cycle::Dir cycle_dir)
+	{
+		auto & sod = const_cast<stencil_op<sten> &>(so);
+		auto & bd = const_cast<grid_func &>(b);
+		auto it = sets.find(std::make_pair(std::is_same<sten, seven_pt>::value, so.shape(0)));
+		if (it == sets.end() || !it->second) { log::error << "plane relaxation: run before setup" << std::endl; return; }
+		cedar_amd_planes_run(it->second, sod.data(), x.data(), bd.data(), cycle_dir == cycle::Dir::UP ? BMG_UP : BMG_DOWN);
+	}
+protected:
+	static int dir() { return rdir == relax_dir::xy ? 0 : rdir == relax_dir::xz ? 1 : 2; }
+	std::map<std::pair<bool, len_t>, cedar_amd_planes *> sets;
+};
+
 using kman_ptr = std::shared_ptr<kernel_manager>;
 inline kman_ptr build_kernel_manager(std::shared_ptr<kernel_params> params)
 {
 	auto km = std::make_shared<kernel_manager>(params);
 	km->add<kernels::point_relax<stypes>, rbgs>("hip");
+	km->add<kernels::plane_relax<stypes, relax_dir::xy>, planes<relax_dir::xy>>("hip");
+	km->add<kernels::plane_relax<stypes, relax_dir::xz>, planes<relax_dir::xz>>("hip");
+	km->add<kernels::plane_relax<stypes, relax_dir::yz>, planes<relax_dir::yz>>("hip");
 	km->add<kernels::residual<stypes>, residual_f90>("hip");
 	km->add<kernels::restriction<stypes>, restrict_f90>("hip");
 	km->add<kernels::interp_add<stypes>, interp_f90>("hip");

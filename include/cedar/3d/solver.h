@@ -63,16 +63,38 @@ public:
 		this->ABD = grid_func::matrix(abd_len_0, nx * ny * nz);
 		this->bbd = new real_t[this->ABD.len(1)];
 	}
+	template <relax_dir d> using plane_relax = kernels::plane_relax<stypes, d>;
+	using rt = ml_settings::relax_type;
+	// include/cedar/multilevel.h:145-160
 	template <class sten> void setup_relax_level(level3<sten> & level)
 	{
-		if (this->settings.relaxation != ml_settings::relax_type::point)
-			log::error << "cdr3::solver: only point relaxation is implemented (plane relaxation is out of scope)" << std::endl;
-		this->kman->template setup<kernels::point_relax<stypes>>(level.A, level.SOR[0]);
+		const auto r = this->settings.relaxation;
+		if (r == rt::point) this->kman->template setup<kernels::point_relax<stypes>>(level.A, level.SOR[0]);
+		else if (!this->settings.planes()) log::error << "cdr3::solver: relaxation must be point or plane-xy / -xz / -yz / -xyz" << std::endl;
+		if (r == rt::plane_xy || r == rt::plane_xyz) this->kman->template setup<plane_relax<relax_dir::xy>>(level.A);
+		if (r == rt::plane_xz || r == rt::plane_xyz) this->kman->template setup<plane_relax<relax_dir::xz>>(level.A);
+		if (r == rt::plane_yz || r == rt::plane_xyz) this->kman->template setup<plane_relax<relax_dir::yz>>(level.A);
 	}
+	// include/cedar/multilevel.h:165-222: plane-xyz runs xy, yz, xz on the way down and xz, yz, xy on the way up
 	template <class sten> void smooth(level3<sten> & level, const stencil_op<sten> & A, grid_func & x, const grid_func & b, cycle::Dir dir)
 	{
 		const int n = dir == cycle::Dir::DOWN ? this->settings.nrelax_pre : this->settings.nrelax_post;
-		for (int i = 0; i < n; i++) this->kman->template run<kernels::point_relax<stypes>>(A, x, b, level.SOR[0], dir);
+		const auto r = this->settings.relaxation;
+		for (int i = 0; i < n; i++) {
+			if (!this->settings.planes()) {
+				this->kman->template run<kernels::point_relax<stypes>>(A, x, b, level.SOR[0], dir);
+			} else if (r == rt::plane_xyz && dir == cycle::Dir::DOWN) {
+				this->kman->template run<plane_relax<relax_dir::xy>>(A, x, b, dir);
+				this->kman->template run<plane_relax<relax_dir::yz>>(A, x, b, dir);
+				this->kman->template run<plane_relax<relax_dir::xz>>(A, x, b, dir);
+			} else if (r == rt::plane_xyz) {
+				this->kman->template run<plane_relax<relax_dir::xz>>(A, x, b, dir);
+				this->kman->template run<plane_relax<relax_dir::yz>>(A, x, b, dir);
+				this->kman->template run<plane_relax<relax_dir::xy>>(A, x, b, dir);
+			} else if (r == rt::plane_xy) this->kman->template run<plane_relax<relax_dir::xy>>(A, x, b, dir);
+			else if (r == rt::plane_xz) this->kman->template run<plane_relax<relax_dir::xz>>(A, x, b, dir);
+			else this->kman->template run<plane_relax<relax_dir::yz>>(A, x, b, dir);
+		}
 	}
 	void download(std::size_t l)
 	{
@@ -107,8 +129,12 @@ protected:
 		st.tol = this->settings.tol;
 		st.min_coarse = this->settings.min_coarse;
 		st.cycle = this->settings.cycle;
-		if (this->settings.relaxation != ml_settings::relax_type::point)
-			log::error << "cdr3::solver: only point relaxation is implemented on the GPU path" << std::endl;
+		st.relaxation = static_cast<int>(this->settings.relaxation); // point 0, plane-xy .. plane-xyz 4..7 as in cedar_amd.h
+		{
+			cedar_amd_settings pst = plane_settings(*this->kman->get_params()->plane_config);
+			st.plane_relaxation = pst.relaxation; st.plane_nrelax_pre = pst.nrelax_pre; st.plane_nrelax_post = pst.nrelax_post;
+			st.plane_max_iter = pst.max_iter; st.plane_min_coarse = pst.min_coarse; st.plane_tol = pst.tol;
+		}
 		BMG_get_bc(this->kman->get_params()->per_mask(), &st.ibc);
 		this->h = cedar_amd_solver_create(3, fop.shape(0), fop.shape(1), fop.shape(2), stencil_ndirs<fsten>::value, fop.data(), 0, &st);
 		if (!this->h)

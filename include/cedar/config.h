@@ -42,6 +42,17 @@ public:
 		return out;
 	}
 	template <class T> void set(const std::string & path, T v) { std::ostringstream o; o << v; scalars[path] = o.str(); }
+	// the sub-object at `path` as a configuration of its own (reference config::getconf); nullptr if absent
+	std::shared_ptr<config> getconf(const std::string & path) const
+	{
+		auto sub = std::make_shared<config>(empty_tag());
+		const std::string pre = path + ".";
+		for (auto & kv : scalars)
+			if (kv.first.compare(0, pre.size(), pre) == 0) sub->scalars[kv.first.substr(pre.size())] = kv.second;
+		return sub->scalars.empty() ? nullptr : sub;
+	}
+	struct empty_tag {};
+	explicit config(empty_tag) {}
 private:
 	template <class T> static T conv(const std::string & s)
 	{
@@ -97,6 +108,7 @@ template <> inline std::string config::conv<std::string>(const std::string & s) 
 struct kernel_params {
 	std::array<bool, 3> periodic{{false, false, false}};
 	bool relax_symmetric = true, definite = true;
+	std::shared_ptr<config> plane_config; // include/cedar/kernel_params.h:32
 	int per_mask() const { int m = 0; for (int i = 0; i < 3; i++) if (periodic[i]) m |= 1 << i; return m; }
 };
 inline std::shared_ptr<kernel_params> build_kernel_params(config & conf)
@@ -104,12 +116,19 @@ inline std::shared_ptr<kernel_params> build_kernel_params(config & conf)
 	auto p = std::make_shared<kernel_params>();
 	auto per = conf.getvec<int>("grid.periodic");
 	for (std::size_t i = 0; i < per.size() && i < 3; i++) p->periodic[i] = per[i] != 0;
+	p->plane_config = conf.getconf("plane-config"); // src/kernel_params.cc:72-78
+	if (p->plane_config == nullptr) {
+		p->plane_config = std::make_shared<config>(config::empty_tag());
+		p->plane_config->set("solver.relaxation", "line-xy");
+		p->plane_config->set("solver.max-iter", 1);
+	}
 	return p;
 }
 
 // reference src/multilevel_settings.cc:15-61
 struct ml_settings {
-	enum class relax_type { point, line_x, line_y, line_xy };
+	enum class relax_type { point, line_x, line_y, line_xy, plane_xy, plane_xz, plane_yz, plane_xyz };
+	bool planes() const { return relaxation >= relax_type::plane_xy; }
 	relax_type relaxation = relax_type::point;
 	int nrelax_pre = 2, nrelax_post = 1, num_levels = -1, maxiter = 10, min_coarse = 3;
 	int cycle = 0; // 0 = v, 1 = f
@@ -121,6 +140,10 @@ struct ml_settings {
 		else if (r == "line-x") relaxation = relax_type::line_x;
 		else if (r == "line-y") relaxation = relax_type::line_y;
 		else if (r == "line-xy") relaxation = relax_type::line_xy;
+		else if (r == "plane-xy") relaxation = relax_type::plane_xy; // src/multilevel_settings.cc:10-13
+		else if (r == "plane-xz") relaxation = relax_type::plane_xz;
+		else if (r == "plane-yz") relaxation = relax_type::plane_yz;
+		else if (r == "plane-xyz") relaxation = relax_type::plane_xyz;
 		else log::error << "invalid relaxation type: " << r << std::endl;
 		auto cyc = conf.get<std::string>("solver.cycle.type", "v");
 		if (cyc == "v") cycle = 0;

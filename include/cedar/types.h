@@ -48,6 +48,10 @@ inline stream error{&std::cerr, true};
 inline stream debug{&std::cout, false};
 }
 namespace cycle { enum class Dir { DOWN = 0, UP = 1 }; }
-enum class relax_dir { x, y };
+enum class relax_dir { x, y, xy, xz, yz }; // include/cedar/types.h:25
+template <relax_dir rdir> struct relax_dir_name { static constexpr const char * value = ""; };
+template <> struct relax_dir_name<relax_dir::xy> { static constexpr const char * value = "xy"; };
+template <> struct relax_dir_name<relax_dir::xz> { static constexpr const char * value = "xz"; };
+template <> struct relax_dir_name<relax_dir::yz> { static constexpr const char * value = "yz"; };
 }
 #endif

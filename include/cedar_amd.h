@@ -214,7 +214,9 @@ void cedar_amd_box_copy(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, 
 typedef struct cedar_amd_solver cedar_amd_solver;
 
 enum { CEDAR_AMD_RELAX_POINT = 0, CEDAR_AMD_RELAX_LINE_X = 1, CEDAR_AMD_RELAX_LINE_Y = 2,
-       CEDAR_AMD_RELAX_LINE_XY = 3 };
+       CEDAR_AMD_RELAX_LINE_XY = 3,
+       /* 3D plane relaxation, include/cedar/multilevel.h:149-159 ("plane-xy" .. "plane-xyz", src/multilevel_settings.cc:10-13) */
+       CEDAR_AMD_RELAX_PLANE_XY = 4, CEDAR_AMD_RELAX_PLANE_XZ = 5, CEDAR_AMD_RELAX_PLANE_YZ = 6, CEDAR_AMD_RELAX_PLANE_XYZ = 7 };
 
 typedef struct {
 	int relaxation;   /* solver.relaxation   (default point)  src/multilevel_settings.cc:15-28 */
@@ -228,6 +230,10 @@ typedef struct {
 	int ibc;          /* boundary code of BMG_get_bc(per_mask) from grid.periodic (src/kernel_params.cc): 0 definite,
 	                     1 periodic in y, 2 in x, 3 in xy; 3D also 5 z, 6 xz, 7 yz, 8 xyz (V-cycle; 3D: even extents in
 	                     the periodic directions on every level that is coarsened) */
+	/* "plane-config" of plane relaxation (src/kernel_params.cc:72-78: line-xy, max-iter 1 unless the configuration
+	 * carries its own block; the other keys default like the solver's) */
+	int plane_relaxation, plane_nrelax_pre, plane_nrelax_post, plane_max_iter, plane_min_coarse;
+	double plane_tol;
 } cedar_amd_settings;
 
 void cedar_amd_default_settings(cedar_amd_settings *s);
@@ -257,6 +263,17 @@ float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const re
 /* n relax sweeps on level 0 alternating DOWN/UP (the roofline microbenchmark);
  * returns elapsed milliseconds (HIP events on the library's stream) */
 float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n);
+
+/* plane relaxation as a kernel of its own -- kernels::plane_relax<stypes, rdir>::setup(so) / run(so, x, b, dir)
+ * (include/cedar/kernels/plane_relax.h:10-33; include/cedar/3d/relax_planes.h:164-246, src/3d/relax_planes.cc).
+ * dir 0 = xy planes, 1 = xz, 2 = yz; plane_settings = the 2D solvers' configuration (NULL: the reference's default
+ * plane-config, line-xy relaxation and one cycle per plane).  so / x / b host or device.  Like the reference, every
+ * plane solver of a direction is built from the coefficients of the LAST plane (copy_coeff, relax_planes.h:80-160). */
+typedef struct cedar_amd_planes cedar_amd_planes;
+cedar_amd_planes *cedar_amd_planes_create(int dir, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so,
+                                          const cedar_amd_settings *plane_settings);
+void cedar_amd_planes_run(cedar_amd_planes *p, const real_t *so, real_t *x, const real_t *b, int updown);
+void cedar_amd_planes_destroy(cedar_amd_planes *p);
 
 /* ------------------------------------------------------------------ 3. rank-to-rank transport (RCCL over xGMI)
  * What the reference's MPI flavour does through its MSG library and MPI collectives -- the ghost-layer exchange

@@ -6,7 +6,8 @@
 //     pairs, registered with add<T,impl>("user") and selected with set<T>("user")) is really run by solver::solve,
 //     and the orchestrated solve reproduces the device-resident one;
 //  3. solver.levels: host views of the device-resident hierarchy equal the hierarchy set up through the manager;
-//  4. the same orchestrated / resident agreement for the 3D solver.
+//  4. the same orchestrated / resident agreement for the 3D solver;
+//  5. and for 3D plane relaxation (plane_relax<rdir> kernels through the registry).
 #include <cstdio>
 #include <fstream>
 #include <cedar/2d/solver.h>
@@ -100,13 +101,32 @@ int main(int argc, char ** argv)
 		s3.solve(b3);
 		h3_orc = s3.history;
 	}
+	// ---- 5. 3D plane relaxation ("plane-xyz" with the default plane configuration): the plane_relax<rdir> kernels through
+	//         the registry (orchestrated) against the resident solver
+	std::vector<real_t> hp_res, hp_orc;
+	{
+		auto pconf = std::make_shared<config>(config::empty_tag());
+		pconf->set("solver.relaxation", "plane-xyz");
+		pconf->set("solver.max-iter", 4);
+		auto so3 = cdr3::gallery::fe(13, 12, 11);
+		cdr3::grid_func b3(13, 12, 11);
+		for (auto k : b3.range(2)) for (auto j : b3.range(1)) for (auto i : b3.range(0)) b3(i, j, k) = 1e-3 * ((int)((i * 7 + j * 3 + k * 5) % 11) - 5);
+		cdr3::solver<cdr3::xxvii_pt> s3(so3, pconf);
+		s3.solve(b3);
+		hp_res = s3.history;
+		s3.force_orchestrated = true;
+		s3.solve(b3);
+		hp_orc = s3.history;
+	}
 	std::printf("{\"resident_before\": %d, \"resident_after\": %d, \"nlevels\": %zu, \"user_setup_calls\": %d, \"user_run_calls\": %d, "
 	            "\"same_level1_operator\": %d, \"x_diff\": %.17g, \"x_max\": %.17g, ",
 	            (int)resident_before, (int)resident_after, nlev, user_relax::nsetup, user_relax::nrun, (int)same_A1, dx, xm);
 	print_hist("hist_resident", h_res);
 	print_hist("hist_user", h_user);
 	print_hist("hist3_resident", h3_res);
-	print_hist("hist3_orchestrated", h3_orc, true);
+	print_hist("hist3_orchestrated", h3_orc);
+	print_hist("hist3_planes_resident", hp_res);
+	print_hist("hist3_planes_orchestrated", hp_orc, true);
 	std::printf("}\n");
 	return 0;
 }

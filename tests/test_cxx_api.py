@@ -83,6 +83,17 @@ def test_registered_hip_kernels_and_user_kernels(tmp_path, oracle):
     np.testing.assert_allclose(got["hist_user"], got["hist_resident"], rtol=1e-12)
     assert got["x_diff"] <= 1e-14 * got["x_max"]
     np.testing.assert_allclose(got["hist3_orchestrated"], got["hist3_resident"], rtol=1e-12)
+    assert len(got["hist3_planes_resident"]) >= 2 and got["hist3_planes_resident"][-1] < 1e-6
+    np.testing.assert_allclose(got["hist3_planes_orchestrated"], got["hist3_planes_resident"], rtol=1e-10)
+    so3 = pb.fe3(13, 12, 11)
+    b3 = np.zeros(so3.shape[1:])
+    kk, jj, ii = np.meshgrid(np.arange(1, 12), np.arange(1, 13), np.arange(1, 14), indexing="ij")
+    b3[1:-1, 1:-1, 1:-1] = 1e-3 * ((ii * 7 + jj * 3 + kk * 5) % 11 - 5)
+    ml3 = oracle.ml_create(so3, relax="plane-xyz")
+    x3 = np.zeros_like(b3)
+    want3 = ml3.solve(b3, x3, maxiter=4)
+    ml3.close()
+    np.testing.assert_allclose(got["hist3_planes_resident"], want3, rtol=1e-8, atol=1e-13)
     # and the resident history is the oracle's
     so5 = pb.poisson2(45, 38)
     bb = np.zeros((40, 47))
