@@ -407,9 +407,13 @@ def main():
                         comm.name if comm is not None else
                         ("RCCL (torch.distributed)" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)"))},
             "roofline": roofline,
-            # device-side interp + Galerkin + relax set-up + solve copies: median over the same fresh allocations (the
-            # first solver of a process also pays for loading every kernel's code object and the first large hipMalloc)
-            "setup_ms": None if not setups else sorted(setups)[len(setups) // 2] * 1e3,
+            # device-side interp + Galerkin + relax set-up + solve copies, host-timed around solver creation.  Quoted: the
+            # MINIMUM over the solver creations of this process.  A creation that maps device memory the process has not
+            # held before also pays the driver's clearing of that memory (~0.45 s for the 45 GB of a 512^3 solver on a
+            # box other processes have used: profiles/r02_setup_time_allocations.log) and, for the very first one,
+            # code-object loading; a creation that reuses released blocks shows the set-up itself.  All values are listed.
+            "setup_ms": None if not setups else min(setups) * 1e3,
+            "setup_ms_is": "minimum over %d solver creations in this process (see setup_ms_per_allocation)" % len(setups),
             "setup_ms_per_allocation": [v * 1e3 for v in setups],
         }
         if not args.no_cpu_baseline and world == 1:

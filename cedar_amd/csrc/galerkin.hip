@@ -199,18 +199,23 @@ void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF
                int IIC, int JJC, int KKC, int ifd, hipStream_t st)
 {
 	if (IIC < 3 || JJC < 3 || KKC < 3) return;
-	// default: compile-time specialised product, the fourteen slots of a coarse row in one XCD-contiguous launch
+	// default: compile-time specialised product -- through per-coarse-point row sums for a 27-point fine operator
+	// (galerkin3_rows.hip), the fourteen slots of a coarse row in one XCD-contiguous launch for a 7-point one
 	// (galerkin3_unrolled.inc, galerkin3_fused.inc); the table-driven kernel below is the readable statement of the
 	// same sum and stays selectable for cross-checks
 	static const bool generic = getenv("CEDAR_AMD_GALERKIN_GENERIC") && atoi(getenv("CEDAR_AMD_GALERKIN_GENERIC")) != 0;
 	if (!generic) {
-		// measured-slower experimental variants, same coarse operators bit for bit:
-		// CEDAR_AMD_GALERKIN_TILED=1 fine operator staged through LDS (profiles/r01_experiment_galerkin_lds_tiled.log),
-		// CEDAR_AMD_GALERKIN_TWOSTAGE=1 T = A P per fine point, then P^T T (profiles/r01_experiment_galerkin_twostage.log)
+		// measured-slower experimental variant, same coarse operators bit for bit:
+		// CEDAR_AMD_GALERKIN_TILED=1 fine operator staged through LDS (profiles/r01_experiment_galerkin_lds_tiled.log).
+		// (Round 1's two-stage product per FINE point -- 74 ms for its first stage, profiles/r01_experiment_galerkin_twostage.log --
+		// is superseded by the per-COARSE-point row sums below.)
 		const char *e3 = getenv("CEDAR_AMD_GALERKIN_TILED");
 		if (e3 && atoi(e3) == 1 && galerkin3_tiled(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
-		const char *e2 = getenv("CEDAR_AMD_GALERKIN_TWOSTAGE");
-		if (e2 && atoi(e2) == 1 && galerkin3_twostage(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
+		// 27-point fine operator: row sums per coarse point, then the contraction (galerkin3_rows.hip; 512^3: 55 -> 28 ms);
+		// CEDAR_AMD_GALERKIN_ROWS=0 keeps the one-stage launch, =1 forces the row sums for a 7-point operator too
+		const char *e1 = getenv("CEDAR_AMD_GALERKIN_ROWS");
+		const bool rows = e1 ? atoi(e1) == 1 : ifd != 1;
+		if (rows && galerkin3_rows(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
 		if (ifd == 1) galerkin3_fused7(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, st);
 		else galerkin3_fused27(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, st);
 		return;

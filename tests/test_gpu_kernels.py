@@ -213,10 +213,12 @@ def test_unserved_boundary_codes_are_refused_loudly(K, capfd):
     assert "boundary code -8 is not implemented" in capfd.readouterr().err
 
 
-@pytest.mark.parametrize("shape,nst", [((9, 8, 7), 14), ((13, 9, 10), 4), ((33, 20, 17), 14), ((17, 12, 31), 4)], ids=str)
-def test_two_stage_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeypatch, shape, nst):
-    """the opt-in two-stage product (galerkin3_twostage.hip) keeps the one-stage kernels' summation order: same
-    coarse operator bit for bit, with the whole grid in one slab and with slabs of 4 coarse planes"""
+@pytest.mark.parametrize("shape,nst", [((9, 8, 7), 14), ((13, 9, 10), 4), ((33, 20, 17), 14), ((17, 12, 31), 4), ((3, 4, 5), 14),
+                                       ((130, 6, 9), 14)], ids=str)
+def test_row_sum_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeypatch, shape, nst):
+    """the row-sum product (galerkin3_rows.hip, the default for 27-point fine operators) keeps the one-stage kernels'
+    summation order: same coarse operator bit for bit, with the whole grid in one slab and with slabs of 1 and 3
+    coarse planes (ring of row-sum planes)"""
     import problems as pb
     nx, ny, nz = shape
     g = (nz + 2, ny + 2, nx + 2)
@@ -224,14 +226,15 @@ def test_two_stage_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeyp
     so = pb.random_op(g, nst, 5, zero_ghost=False)
     ci = pb.uniform((26,) + gc, 6, -1, 1)
     out = []
-    for ts, mb in (("0", "2048"), ("1", "2048"), ("1", "1")):
-        monkeypatch.setenv("CEDAR_AMD_GALERKIN_TWOSTAGE", ts)
-        monkeypatch.setenv("CEDAR_AMD_GALERKIN_SCRATCH_MB", mb)
+    for rows, slab in (("0", "32"), ("1", "1000"), ("1", "1"), ("1", "3")):
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_ROWS", rows)
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_SLAB", slab)
         soc = np.zeros((14,) + gc)
         K.galerkin3(so, soc, ci)
         out.append(soc)
     assert np.any(out[0] != 0)
-    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    for o in out[1:]:
+        assert np.array_equal(out[0], o)
 
 
 def _random_cases(nd, count, seed, lo, hi):
