@@ -94,16 +94,10 @@ __device__ __forceinline__ void load_pair9(const real_t *__restrict__ so, const 
 // otherwise.  In-place is safe: a launch writes rows of one parity only, and inside a row every
 // value that a later chunk still has to read "old" has not been written yet.
 template <int BS, bool EFIRST>
-__global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
-                                                   real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                   int II, int JJ, int jb, int nrows)
+__device__ __forceinline__ void relax9_row_task(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                int II, size_t sj, size_t PS, size_t row, real_t *xch, real_t *carry_s)
 {
-	__shared__ real_t xch[BS + 2];
-	__shared__ real_t carry_s;
-	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nrows);
-	if (L >= (unsigned)nrows) return;
-	const size_t sj = II, PS = (size_t)II * JJ;
-	const size_t row = (size_t)(1 + jb + 2 * (int)L) * sj;
 	const int npairs = (II - 2 + 1) / 2;
 	const int nchunks = (npairs + BS - 1) / BS;
 	const int t = threadIdx.x;
@@ -118,7 +112,7 @@ __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so,
 			load_pair9(so, qf, q, row, sj, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
 			ldpair2(sor + PS + row + ie, true, sre, sro);
 		}
-		const real_t carry = carry_s; // written by the previous chunk iteration (unused in the first)
+		const real_t carry = *carry_s; // written by the previous chunk iteration (unused in the first)
 		if (EFIRST) {
 			if (e_ok) { e_new = offdiag9(qfe, ce, qe) * sre; xch[t] = e_new; }
 			__syncthreads();
@@ -127,7 +121,7 @@ __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so,
 				if (io + 1 <= II - 2) qo[1][2] = (t < BS - 1) ? xch[t + 1] : carry; // next pair's fresh even point
 				o_new = offdiag9(qfo, co, qo) * sro;
 			}
-			if (t == 0) carry_s = e_new; // first even point of this chunk, for the chunk below
+			if (t == 0) *carry_s = e_new; // first even point of this chunk, for the chunk below
 		} else {
 			if (o_ok) { o_new = offdiag9(qfo, co, qo) * sro; xch[t + 1] = o_new; }
 			__syncthreads();
@@ -136,7 +130,7 @@ __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so,
 				if (o_ok) qe[1][2] = o_new;
 				e_new = offdiag9(qfe, ce, qe) * sre;
 			}
-			if (t == BS - 1) carry_s = o_new;
+			if (t == BS - 1) *carry_s = o_new;
 		}
 		if (e_ok) {
 			if (o_ok) {
@@ -146,6 +140,55 @@ __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so,
 				q[row + ie] = e_new;
 		}
 		__syncthreads(); // stores + carry visible before the next chunk loads / reads them
+	}
+}
+
+// rows j = j0 + jstep * L (0-based incl. ghost), L < nrows; the row classes use j0 = 1 + jb, jstep = 2
+template <int BS, bool EFIRST>
+__global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                   real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                   int II, int JJ, int j0, int jstep, int nrows)
+{
+	__shared__ real_t xch[BS + 2];
+	__shared__ real_t carry_s;
+	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nrows);
+	if (L >= (unsigned)nrows) return;
+	const size_t sj = II, PS = (size_t)II * JJ;
+	relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(j0 + jstep * (int)L) * sj, xch, &carry_s);
+}
+
+// Band-fused sweep: both row classes in ONE launch.  The sweep relaxes the rows of class F (parity jbF) before those
+// of class S; an S row reads the fresh values of its two F neighbours and nothing else changes under it.  A workgroup
+// owns a run of consecutive F rows [f0, f1) and walks F(f0), F(f0+1), S between them, F(f0+2), S, ...: the three
+// operator rows both classes need (ks, ksw, knw of the upper row: 3 of the 8 slot-rows a row task reads) and the q rows
+// are used again one task later instead of being streamed once per launch.  The S row between two runs has its F
+// neighbours in different workgroups and is left to a small second launch (relax9_rows, jstep = 2*frun).  Same
+// arithmetic per point on the same values => identical to the two-launch order.  (2D analogue of relax27_plane.)
+template <int BS, bool EFIRST>
+__global__ __launch_bounds__(BS) void relax9_band(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                   real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                   int II, int JJ, int jbF, int frun, int nrun)
+{
+	__shared__ real_t xch[BS + 2];
+	__shared__ real_t carry_s;
+	const unsigned run = xcd_remap(blockIdx.x, (unsigned)nrun);
+	if (run >= (unsigned)nrun) return;
+	const size_t sj = II, PS = (size_t)II * JJ;
+	const int nF = (JJ - 2 - jbF + 1) / 2, nS = (JJ - 2 - (1 - jbF) + 1) / 2;
+	const int f0 = (int)run * frun, f1 = min(nF, f0 + frun);
+	for (int f = f0; f < f1; f++) {
+		relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(1 + jbF + 2 * f) * sj, xch, &carry_s);
+		// the S row both of whose F neighbours are now done (a missing neighbour = ghost row):
+		//   jbF = 0: S row g (j = 2+2g) lies between F rows g, g+1  -> after F(f): g = f-1 (f > f0)
+		//   jbF = 1: S row g (j = 1+2g) lies between F rows g-1, g  -> after F(f): g = f   (f > f0, or f = 0)
+		const int g = jbF ? f : f - 1;
+		const bool have = jbF ? (f > f0 || f == 0) : (f > f0);
+		if (have && g >= 0 && g < nS) // (the row task ends with a barrier: the F stores are visible)
+			relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(2 - jbF + 2 * g) * sj, xch, &carry_s);
+	}
+	if (f1 == nF && f1 > f0) { // the S row beyond the last F row (its other neighbour is the ghost row)
+		const int g = jbF ? nF : nF - 1;
+		if (g < nS) relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(2 - jbF + 2 * g) * sj, xch, &carry_s);
 	}
 }
 
@@ -203,20 +246,55 @@ __global__ __launch_bounds__(256) void relax5_colour(const real_t *__restrict__ 
 // one row class (jb = parity of the 0-based row minus 1) of the nine-point sweep, both i-colours;
 // efirst: even 1-based i first (the DOWN order of the 2D sweep).  Domain-decomposed runs exchange
 // halos between row classes.
+template <int BS>
+static void launch_rows9(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
+                         int j0, int jstep, int nrows, hipStream_t st)
+{
+	if (nrows <= 0) return;
+	const unsigned grid = xcd_grid((unsigned)nrows);
+	if (efirst) hipLaunchKernelGGL((relax9_rows<BS, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, j0, jstep, nrows);
+	else hipLaunchKernelGGL((relax9_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, j0, jstep, nrows);
+}
+
 void relax2_pass9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                   int II, int JJ, int jb, int efirst, hipStream_t st)
 {
-	int nrows = (JJ - 2 - jb + 1) / 2;
-	if (nrows <= 0) return;
-	unsigned grid = xcd_grid((unsigned)nrows);
-	const int npairs = (II - 2 + 1) / 2;
-	if (npairs <= 64) {
-		if (efirst) hipLaunchKernelGGL((relax9_rows<64, true>), dim3(grid), dim3(64), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-		else hipLaunchKernelGGL((relax9_rows<64, false>), dim3(grid), dim3(64), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-	} else {
-		if (efirst) hipLaunchKernelGGL((relax9_rows<256, true>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
-		else hipLaunchKernelGGL((relax9_rows<256, false>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jb, nrows);
+	const int nrows = (JJ - 2 - jb + 1) / 2;
+	if ((II - 2 + 1) / 2 <= 64) launch_rows9<64>(efirst != 0, so, qf, q, sor, II, JJ, 1 + jb, 2, nrows, st);
+	else launch_rows9<256>(efirst != 0, so, qf, q, sor, II, JJ, 1 + jb, 2, nrows, st);
+}
+
+// F rows per workgroup of the band-fused sweep; 0 = two launches per sweep (one per row class).
+// CEDAR_AMD_FRUN2 overrides (0 = never; n = runs of n rows wherever the grid has >= 4 runs per class).
+static int band_frun(int II, int JJ)
+{
+	const char *e = getenv("CEDAR_AMD_FRUN2"); // read per call: the tests switch it between cases
+	const int ny = JJ - 2;
+	if (e) {
+		const int frun = atoi(e);
+		return (frun <= 0 || ny < 8 * frun) ? 0 : frun;
 	}
+	// measured (profiles/r02_experiment_band_fused_relax9.log): 4096^2 -4.5 % at runs of 4, slower from 8 on (a 2D grid has
+	// only ny/2 row tasks per class: long runs leave compute units idle), slower at 2048^2 and below at any run length
+	return (ny >= 4096 && II - 2 >= 2048) ? 4 : 0;
+}
+
+// whole nine-point sweep
+static void relax2_sweep9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, bool down, hipStream_t st)
+{
+	const int frun = band_frun(II, JJ);
+	if (frun == 0 || (II - 2 + 1) / 2 <= 64) {
+		for (int c = 0; c < 2; c++) // DOWN: rows J=2,4,.. first (LSTART=2), even 1-based i first
+			relax2_pass9(so, qf, q, sor, II, JJ, down ? c : 1 - c, down, st);
+		return;
+	}
+	const int jbF = down ? 0 : 1;
+	const int nF = (JJ - 2 - jbF + 1) / 2, nrun = (nF + frun - 1) / frun;
+	const unsigned grid = xcd_grid((unsigned)nrun);
+	if (down) hipLaunchKernelGGL((relax9_band<256, true>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun);
+	else hipLaunchKernelGGL((relax9_band<256, false>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun);
+	// S rows between runs: jbF = 0: j = 2 frun (r+1); jbF = 1: j = 1 + 2 frun (r+1), r = 0 .. nrun-2
+	launch_rows9<256>(down, so, qf, q, sor, II, JJ, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, st);
 }
 
 // recompute the points of column icol (0-based incl. ghost) on the rows of class jb: used after the
@@ -265,8 +343,7 @@ void relax2_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 	if (II < 3 || JJ < 3) return;
 	const bool down = (updown == BMG_DOWN);
 	if (nstncl == 5) {
-		for (int c = 0; c < 2; c++) // DOWN: rows J=2,4,.. first (LSTART=2), even 1-based i first
-			relax2_pass9(so, qf, q, sor, II, JJ, down ? c : 1 - c, down, st);
+		relax2_sweep9(so, qf, q, sor, II, JJ, down, st);
 	} else {
 		for (int c = 0; c < 2; c++)
 			relax2_colour5(so, qf, q, sor, II, JJ, down ? 2 + c : 3 - c /* LSTART..LEND */, st);

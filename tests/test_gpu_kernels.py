@@ -106,6 +106,26 @@ def test_plane_fused_relax_matches_four_pass_order(K, oracle, monkeypatch, shape
         assert np.array_equal(got, want), (shape, frun, ud, np.max(np.abs(got - want)))
 
 
+@pytest.mark.parametrize("frun", [1, 2, 3, 0])
+@pytest.mark.parametrize("shape", [(300, 48), (131, 33), (1100, 25), (260, 24)], ids=str)
+def test_band_fused_relax9_matches_two_pass_order(K, oracle, monkeypatch, shape, frun):
+    """the band-fused nine-point sweep (relax9_band + the deferred rows between runs) for several run lengths, odd and
+    even ny, rows of one and of several chunks, both sweep directions: bit-identical to the reference order"""
+    import problems as pb
+    monkeypatch.setenv("CEDAR_AMD_FRUN2", str(frun))
+    nx, ny = shape
+    g = (ny + 2, nx + 2)
+    so = pb.random_op(g, 5, 61, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 62, -1, 1), pb.uniform(g, 63, -1, 1)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip2(so, sor)
+    for ud in (0, 1):
+        want, got = q0.copy(), q0.copy()
+        oracle.relax2(so, qf, want, sor, ud)
+        K.relax2(so, qf, got, sor, ud)
+        assert np.array_equal(got, want), (shape, frun, ud, np.max(np.abs(got - want)))
+
+
 @pytest.mark.parametrize("shape", [(20, 16, 5), (9, 7, 4), (70, 18, 6), (11, 3, 7), (12, 9, 2)], ids=str)
 def test_partial_row_class_passes_compose_to_the_full_pass(shape):
     """cedar_amd_relax3_pass_part: interior rows (part 1) then shell rows (part 2) of a row class equal the
