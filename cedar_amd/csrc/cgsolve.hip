@@ -114,11 +114,13 @@ __global__ __launch_bounds__(256) void setup_cg2_kernel(const real_t *__restrict
 }
 
 __global__ __launch_bounds__(64) void solve_cg2_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ,
-                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1, int use_lds)
+                                                        const real_t *__restrict__ abd, real_t *__restrict__ bbd, int nabd1, int use_lds,
+                                                        size_t bstride, int nabd2)
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int I1 = II - 1, J1 = JJ - 1, I2 = I1 - 1;
 	const int n = I2 * (J1 - 1);
+	q += bstride * blockIdx.x; qf += bstride * blockIdx.x; bbd += (size_t)nabd2 * blockIdx.x; // batch item (common.h Batch)
 	for (int kk = threadIdx.x; kk < n; kk += blockDim.x) {
 		const int i = kk % I2 + 1, j = kk / I2 + 1; // 0-based
 		bbd[kk] = qf[(size_t)i + (size_t)II * j];
@@ -137,11 +139,13 @@ void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int na
 	hipLaunchKernelGGL(setup_cg2_kernel, dim3(1), dim3(256), 0, st, so, II, JJ, nstncl, abd, nabd1, nabd2, info);
 }
 
-void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st)
+void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st,
+               Batch bt)
 {
 	size_t shm = ((size_t)nabd1 * nabd2 + nabd2 + 2) * sizeof(real_t);
 	int use_lds = shm <= 60 * 1024;
-	hipLaunchKernelGGL(solve_cg2_kernel, dim3(1), dim3(64), use_lds ? shm : 0, st, q, qf, II, JJ, abd, bbd, nabd1, use_lds);
+	hipLaunchKernelGGL(solve_cg2_kernel, dim3(bt.n), dim3(64), use_lds ? shm : 0, st, q, qf, II, JJ, abd, bbd, nabd1, use_lds,
+	                   bt.stride, nabd2);
 }
 
 // ------------------------------------------------------------------ 3D

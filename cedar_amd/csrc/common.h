@@ -80,6 +80,14 @@ void relax3_release(const real_t *so);
 // build the row-interleaved copy from the Cedar-layout operator (14 slots) and 1/diag plane (relax3d.hip)
 void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, int JJ, int KK, hipStream_t st);
 
+// A batch of independent problems on ONE operator (plane relaxation: the planes of one colour, solver.cpp): the 2D
+// solve-phase kernels take the batch item from blockIdx.y (row kernels with a one-dimensional grid) or blockIdx.z and
+// offset their VECTOR arguments by `stride` doubles per item; operator arrays are shared.  n = 1: a single problem.
+struct Batch {
+	int n = 1;
+	size_t stride = 0;
+};
+
 // ---- kernel launchers (device pointers, asynchronous on `st`) ----
 // relax3d.hip
 void setup_recip(const real_t *so_diag, real_t *sor_msor, size_t II, size_t JJ, size_t KK, hipStream_t st);
@@ -98,10 +106,10 @@ void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t 
                     int II, int JJ, int KK, int pts, hipStream_t st);
 // relax2d.hip
 void relax2_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-               int II, int JJ, int nstncl, int updown, hipStream_t st);
+               int II, int JJ, int nstncl, int updown, hipStream_t st, Batch bt = Batch());
 // residual.hip
 void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
-               int II, int JJ, int nstncl, hipStream_t st);
+               int II, int JJ, int nstncl, hipStream_t st, Batch bt = Batch());
 void residual3(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
                int II, int JJ, int KK, int nstncl, hipStream_t st);
 // pieces of the 2D sweep / set-up for domain-decomposed runs (relax2d.hip, setup_interp.hip)
@@ -159,11 +167,12 @@ void matvec3(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int 
 // sum of squares over the interior -> *out (deterministic two-stage tree); scratch >= 4096 doubles
 void sumsq_interior(const real_t *v, int II, int JJ, int KK, real_t *scratch, real_t *out, hipStream_t st);
 // transfer.hip
-void restrict2(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int IIC, int JJC, hipStream_t st);
+void restrict2(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int IIC, int JJC, hipStream_t st,
+               Batch bf = Batch(), Batch bc = Batch()); // batch strides of the fine / coarse vectors
 void restrict3(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int KK,
                int IIC, int JJC, int KKC, hipStream_t st);
 void interp_add2(real_t *q, const real_t *qc, real_t *res, const real_t *so, const real_t *ci,
-                 int IIC, int JJC, int IIF, int JJF, hipStream_t st);
+                 int IIC, int JJC, int IIF, int JJF, hipStream_t st, Batch bf = Batch(), Batch bc = Batch());
 void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, const real_t *ci,
                  int IIC, int JJC, int KKC, int IIF, int JJF, int KKF, hipStream_t st);
 void box_copy(real_t *arr, int II, int JJ, int KK, int nplanes, int nboxes, const int *boxes,
@@ -195,7 +204,8 @@ void zero_fill(real_t *p, size_t n, hipStream_t st);
 void setup_lines_x(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
 void setup_lines_y(const real_t *so, real_t *sor, int II, int JJ, hipStream_t st, int fold = 0);
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0, const real_t *pf = nullptr);
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0, const real_t *pf = nullptr,
+                   Batch bt = Batch()); // batches: Dirichlet lines only
 // scan-ordered copy of the line factors for the resident solver (lines.hip line_pttrs_pf); 0 doubles = not used
 size_t lines_permuted_doubles(int n, int nlines);
 void lines_permute(const real_t *sor, real_t *pf, int n, int ld, int nlines, size_t PS, hipStream_t st);
@@ -204,13 +214,14 @@ size_t ylines_scratch_doubles(int II, int JJ);
 void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, real_t *scratch,
                    int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn = 0);
 // y-lines on transposed arrays (lines.hip): transposed operator planes, transposed right-hand side, scratch for q^T
-void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st);
+void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st, Batch bt = Batch());
 void setup_lines_yt(const real_t *so, real_t *sot, int II, int JJ, int nstncl, hipStream_t st);
 void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt, const real_t *sor,
-                    int II, int JJ, int nstncl, int updown, hipStream_t st, const real_t *pf = nullptr);
+                    int II, int JJ, int nstncl, int updown, hipStream_t st, const real_t *pf = nullptr, Batch bt = Batch());
 // cgsolve.hip
 void setup_cg2(const real_t *so, int II, int JJ, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
-void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);
+void solve_cg2(real_t *q, const real_t *qf, int II, int JJ, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st,
+               Batch bt = Batch()); // bbd: nabd2 doubles per batch item
 void setup_cg3(const real_t *so, int II, int JJ, int KK, int nstncl, real_t *abd, int nabd1, int nabd2, int *info, hipStream_t st);
 void solve_cg3(real_t *q, const real_t *qf, int II, int JJ, int KK, const real_t *abd, real_t *bbd, int nabd1, int nabd2, hipStream_t st);
 // gallery.hip (device-side generators of the reference's gallery operators)

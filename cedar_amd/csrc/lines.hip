@@ -398,13 +398,14 @@ template <int BS, bool NINE, bool SM = false, bool YT = false, bool PERM = false
 __global__ __launch_bounds__(BS) void relax_lines_x_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                             real_t *__restrict__ q, const real_t *__restrict__ sor,
                                                             int II, int JJ, int jb, int nlines, int dbg,
-                                                            const real_t *__restrict__ pf)
+                                                            const real_t *__restrict__ pf, size_t bstride)
 {
 	extern __shared__ __attribute__((aligned(16))) real_t lds[];
 	const int npad = (II - 2) + ((II - 2) >> 3) + 1;
 	real_t *y = lds, *wa = lds + npad, *wc = wa + 16, *cs = wc + 16;
 	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nlines);
 	if (L >= (unsigned)nlines) return;
+	qf += bstride * blockIdx.y; q += bstride * blockIdx.y; // batch item (common.h Batch)
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const size_t row = (size_t)(1 + jb + 2 * (int)L) * sj;
 	const int n = II - 2;
@@ -521,50 +522,52 @@ static bool lds_ok(int n, const char *who)
 
 template <int BS, bool NINE, bool SM, bool YT, bool PERM>
 static void launch_x_kp(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, int nlines,
-                        hipStream_t st, const real_t *pf)
+                        hipStream_t st, const real_t *pf, Batch bt)
 {
 	size_t shm = line_lds_doubles(II - 2) * sizeof(real_t);
 	auto k = relax_lines_x_kernel<BS, NINE, SM, YT, PERM>;
 	if (shm > 64 * 1024) CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
 	const char *ed = getenv("CEDAR_AMD_LINE_DBG"); // timing experiments only (1: no solve, 2: no right-hand side)
-	hipLaunchKernelGGL(k, dim3(xcd_grid(nlines)), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines, ed ? atoi(ed) : 0, pf);
+	hipLaunchKernelGGL(k, dim3(xcd_grid(nlines), bt.n), dim3(BS), shm, st, so, qf, q, sor, II, JJ, jb, nlines, ed ? atoi(ed) : 0, pf,
+	                   bt.stride);
 }
 
 // pf != nullptr: the scan-ordered factor copy of this line direction (lines_permute), Dirichlet lines of the 256-lane kernel
 template <int BS, bool NINE, bool SM, bool YT = false>
 static void launch_x_k(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, int nlines,
-                       hipStream_t st, const real_t *pf)
+                       hipStream_t st, const real_t *pf, Batch bt)
 {
-	if (!SM && pf && BS >= 256) launch_x_kp<BS, NINE, false, YT, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
-	else launch_x_kp<BS, NINE, SM, YT, false>(so, qf, q, sor, II, JJ, jb, nlines, st, nullptr);
+	if (!SM && pf && BS >= 256) launch_x_kp<BS, NINE, false, YT, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
+	else launch_x_kp<BS, NINE, SM, YT, false>(so, qf, q, sor, II, JJ, jb, nlines, st, nullptr, bt);
 }
 
 template <int BS>
 static void launch_x_n(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                       int nstncl, int jb, hipStream_t st, bool sm, bool yt, const real_t *pf)
+                       int nstncl, int jb, hipStream_t st, bool sm, bool yt, const real_t *pf, Batch bt)
 {
 	int nlines = (JJ - 2 - jb + 1) / 2;
 	if (nlines <= 0) return;
 	if (yt) { // Dirichlet only
-		if (nstncl == 5) launch_x_k<BS, true, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
-		else launch_x_k<BS, false, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+		if (nstncl == 5) launch_x_k<BS, true, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
+		else launch_x_k<BS, false, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
 	} else if (nstncl == 5) {
-		if (sm) launch_x_k<BS, true, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
-		else launch_x_k<BS, true, false>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+		if (sm) launch_x_k<BS, true, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
+		else launch_x_k<BS, true, false>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
 	} else {
-		if (sm) launch_x_k<BS, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
-		else launch_x_k<BS, false, false>(so, qf, q, sor, II, JJ, jb, nlines, st, pf);
+		if (sm) launch_x_k<BS, false, true>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
+		else launch_x_k<BS, false, false>(so, qf, q, sor, II, JJ, jb, nlines, st, pf, bt);
 	}
 }
 
 static void launch_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                     int nstncl, int jb, hipStream_t st, bool sm = false, bool yt = false, const real_t *pf = nullptr)
+                     int nstncl, int jb, hipStream_t st, bool sm = false, bool yt = false, const real_t *pf = nullptr,
+                     Batch bt = Batch())
 {
 	switch (line_bs(II - 2)) {
-	case 64: launch_x_n<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf); break;
-	case 512: launch_x_n<512>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf); break;
-	case 1024: launch_x_n<1024>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf); break;
-	default: launch_x_n<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf);
+	case 64: launch_x_n<64>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf, bt); break;
+	case 512: launch_x_n<512>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf, bt); break;
+	case 1024: launch_x_n<1024>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf, bt); break;
+	default: launch_x_n<256>(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, yt, pf, bt);
 	}
 }
 
@@ -594,7 +597,7 @@ void lines_permute(const real_t *sor, real_t *pf, int n, int ld, int nlines, siz
 }
 
 void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn, const real_t *pf)
+                   int II, int JJ, int nstncl, int updown, hipStream_t st, int ipn, const real_t *pf, Batch bt)
 {
 	if (II < 3 || JJ < 3) return;
 	if (!lds_ok(II - 2, "relax_lines_x")) return;
@@ -602,7 +605,7 @@ void relax_lines_x(const real_t *so, const real_t *qf, real_t *q, const real_t *
 	for (int c = 0; c < 2; c++) {
 		// DOWN: lines J = 3,5,.. first (0-based rows 2,4,.. => jb = 1), then J = 2,4,..
 		int jb = (updown == BMG_DOWN) ? 1 - c : c;
-		launch_x(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, false, sm ? nullptr : pf);
+		launch_x(so, qf, q, sor, II, JJ, nstncl, jb, st, sm, false, sm ? nullptr : pf, bt);
 		if (sm) wrap2(q, II, JJ, 1, ipn == 3, 1, st);
 	}
 	if (ipn == 1) wrap2(q, II, JJ, 1, 1, 0, st);
@@ -762,9 +765,11 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 // the transposed grid.  Same right-hand-side term order, same scan: bit-identical to relax_lines_y.  8192^2:
 // 2 x 1534 us (gather + solve + scatter per colour) -> 2 x 750 us + two transposes of q.
 // out(j,i) = in(i,j), whole arrays with ghosts: in is (II fast, JJ), out is (JJ fast, II)
-__global__ __launch_bounds__(256) void transpose2_kernel(const real_t *__restrict__ in, real_t *__restrict__ out, int II, int JJ)
+__global__ __launch_bounds__(256) void transpose2_kernel(const real_t *__restrict__ in, real_t *__restrict__ out, int II, int JJ,
+                                                         size_t bstride)
 {
 	__shared__ real_t tile[64][65];
+	in += bstride * blockIdx.z; out += bstride * blockIdx.z; // batch item (common.h Batch)
 	const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
 	for (int r = ty; r < 64; r += 4) {
@@ -778,9 +783,9 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const real_t *__restric
 	}
 }
 
-void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st)
+void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st, Batch bt)
 {
-	hipLaunchKernelGGL(transpose2_kernel, dim3((II + 63) / 64, (JJ + 63) / 64), dim3(256), 0, st, in, out, II, JJ);
+	hipLaunchKernelGGL(transpose2_kernel, dim3((II + 63) / 64, (JJ + 63) / 64, bt.n), dim3(256), 0, st, in, out, II, JJ, bt.stride);
 }
 
 // sot (JJ fast, II, nstncl planes): plane KS = KW^T, KW = KS^T, KSW = KSW^T, KNW = KNW^T; KO is not read by the sweep
@@ -797,19 +802,19 @@ void setup_lines_yt(const real_t *so, real_t *sot, int II, int JJ, int nstncl, h
 
 // qft = transposed right-hand side (the caller keeps it while qf is unchanged), qt = scratch for the transposed q
 void relax_lines_yt(const real_t *sot, const real_t *qft, real_t *q, real_t *qt, const real_t *sor,
-                    int II, int JJ, int nstncl, int updown, hipStream_t st, const real_t *pf)
+                    int II, int JJ, int nstncl, int updown, hipStream_t st, const real_t *pf, Batch bt)
 {
 	if (II < 3 || JJ < 3) return;
 	if (!lds_ok(JJ - 2, "relax_lines_y")) return;
-	transpose2(q, qt, II, JJ, st);
+	transpose2(q, qt, II, JJ, st, bt);
 	for (int c = 0; c < 2; c++) {
 		const int ib = (updown == BMG_DOWN) ? 1 - c : c; // DOWN: I = 3,5,.. first
 		const int nlines = (II - 2 - ib + 1) / 2;
 		if (nlines <= 0) continue;
 		// transposed grid: JJ is the fast extent, II the number of rows
-		launch_x(sot, qft, qt, sor, JJ, II, nstncl, ib, st, false, true, pf);
+		launch_x(sot, qft, qt, sor, JJ, II, nstncl, ib, st, false, true, pf, bt);
 	}
-	transpose2(qt, q, JJ, II, st);
+	transpose2(qt, q, JJ, II, st, bt);
 }
 
 // ---- pieces of the domain-decomposed line relaxation (cedar_amd/dist2d.py): right-hand sides of the

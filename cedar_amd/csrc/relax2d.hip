@@ -147,12 +147,13 @@ __device__ __forceinline__ void relax9_row_task(const real_t *__restrict__ so, c
 template <int BS, bool EFIRST>
 __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                    real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                   int II, int JJ, int j0, int jstep, int nrows)
+                                                   int II, int JJ, int j0, int jstep, int nrows, size_t bstride)
 {
 	__shared__ real_t xch[BS + 2];
 	__shared__ real_t carry_s;
 	const unsigned L = xcd_remap(blockIdx.x, (unsigned)nrows);
 	if (L >= (unsigned)nrows) return;
+	qf += bstride * blockIdx.y; q += bstride * blockIdx.y; // batch item (common.h Batch)
 	const size_t sj = II, PS = (size_t)II * JJ;
 	relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(j0 + jstep * (int)L) * sj, xch, &carry_s);
 }
@@ -167,12 +168,13 @@ __global__ __launch_bounds__(BS) void relax9_rows(const real_t *__restrict__ so,
 template <int BS, bool EFIRST>
 __global__ __launch_bounds__(BS) void relax9_band(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                    real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                   int II, int JJ, int jbF, int frun, int nrun)
+                                                   int II, int JJ, int jbF, int frun, int nrun, size_t bstride)
 {
 	__shared__ real_t xch[BS + 2];
 	__shared__ real_t carry_s;
 	const unsigned run = xcd_remap(blockIdx.x, (unsigned)nrun);
 	if (run >= (unsigned)nrun) return;
+	qf += bstride * blockIdx.y; q += bstride * blockIdx.y; // batch item (common.h Batch)
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const int nF = (JJ - 2 - jbF + 1) / 2, nS = (JJ - 2 - (1 - jbF) + 1) / 2;
 	const int f0 = (int)run * frun, f1 = min(nF, f0 + frun);
@@ -195,10 +197,11 @@ __global__ __launch_bounds__(BS) void relax9_band(const real_t *__restrict__ so,
 // 9-point residual, pair per lane, 16-byte loads (BMG2_SymStd_residual.f90:88-99)
 __global__ __launch_bounds__(256) void residual9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                        const real_t *__restrict__ q, real_t *__restrict__ res,
-                                                       int II, int JJ, unsigned nrows)
+                                                       int II, int JJ, unsigned nrows, size_t bstride)
 {
 	const unsigned L = xcd_remap(blockIdx.x, nrows);
 	if (L >= nrows) return;
+	qf += bstride * blockIdx.y; q += bstride * blockIdx.y; res += bstride * blockIdx.y; // batch item (common.h Batch)
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const size_t row = (size_t)(L + 1) * sj;
 	for (int p = threadIdx.x; 2 * p + 1 <= II - 2; p += blockDim.x) {
@@ -218,17 +221,19 @@ __global__ __launch_bounds__(256) void residual9_rows(const real_t *__restrict__
 	}
 }
 
-void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st)
+void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st, Batch bt)
 {
 	unsigned nrows = (unsigned)(JJ - 2);
-	hipLaunchKernelGGL(residual9_rows, dim3(xcd_grid(nrows)), dim3((II - 2) / 2 >= 256 ? 256 : 64), 0, st, so, qf, q, res, II, JJ, nrows);
+	hipLaunchKernelGGL(residual9_rows, dim3(xcd_grid(nrows), bt.n), dim3((II - 2) / 2 >= 256 ? 256 : 64), 0, st, so, qf, q, res, II, JJ,
+	                   nrows, bt.stride);
 }
 
 // 5-point red-black, one colour per launch (relax_GS.f90:120-135): colour = mod(j+jo,2)
 __global__ __launch_bounds__(256) void relax5_colour(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                       real_t *__restrict__ q, const real_t *__restrict__ sor,
-                                                      int II, int JJ, int jo)
+                                                      int II, int JJ, int jo, size_t bstride)
 {
+	qf += bstride * blockIdx.z; q += bstride * blockIdx.z; // batch item (common.h Batch)
 	const int j1 = blockIdx.y + 2; // 1-based
 	const int a = blockIdx.x * blockDim.x + threadIdx.x;
 	const int i1 = (j1 + jo) % 2 + 2 + 2 * a;
@@ -248,20 +253,26 @@ __global__ __launch_bounds__(256) void relax5_colour(const real_t *__restrict__ 
 // halos between row classes.
 template <int BS>
 static void launch_rows9(bool efirst, const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ,
-                         int j0, int jstep, int nrows, hipStream_t st)
+                         int j0, int jstep, int nrows, hipStream_t st, Batch bt = Batch())
 {
 	if (nrows <= 0) return;
-	const unsigned grid = xcd_grid((unsigned)nrows);
-	if (efirst) hipLaunchKernelGGL((relax9_rows<BS, true>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, j0, jstep, nrows);
-	else hipLaunchKernelGGL((relax9_rows<BS, false>), dim3(grid), dim3(BS), 0, st, so, qf, q, sor, II, JJ, j0, jstep, nrows);
+	const dim3 grid(xcd_grid((unsigned)nrows), bt.n);
+	if (efirst) hipLaunchKernelGGL((relax9_rows<BS, true>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, j0, jstep, nrows, bt.stride);
+	else hipLaunchKernelGGL((relax9_rows<BS, false>), grid, dim3(BS), 0, st, so, qf, q, sor, II, JJ, j0, jstep, nrows, bt.stride);
+}
+
+static void pass9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jb, bool efirst,
+                  hipStream_t st, Batch bt)
+{
+	const int nrows = (JJ - 2 - jb + 1) / 2;
+	if ((II - 2 + 1) / 2 <= 64) launch_rows9<64>(efirst, so, qf, q, sor, II, JJ, 1 + jb, 2, nrows, st, bt);
+	else launch_rows9<256>(efirst, so, qf, q, sor, II, JJ, 1 + jb, 2, nrows, st, bt);
 }
 
 void relax2_pass9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                   int II, int JJ, int jb, int efirst, hipStream_t st)
 {
-	const int nrows = (JJ - 2 - jb + 1) / 2;
-	if ((II - 2 + 1) / 2 <= 64) launch_rows9<64>(efirst != 0, so, qf, q, sor, II, JJ, 1 + jb, 2, nrows, st);
-	else launch_rows9<256>(efirst != 0, so, qf, q, sor, II, JJ, 1 + jb, 2, nrows, st);
+	pass9(so, qf, q, sor, II, JJ, jb, efirst != 0, st, Batch());
 }
 
 // F rows per workgroup of the band-fused sweep; 0 = two launches per sweep (one per row class).
@@ -280,21 +291,22 @@ static int band_frun(int II, int JJ)
 }
 
 // whole nine-point sweep
-static void relax2_sweep9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, bool down, hipStream_t st)
+static void relax2_sweep9(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, bool down, hipStream_t st,
+                          Batch bt)
 {
 	const int frun = band_frun(II, JJ);
 	if (frun == 0 || (II - 2 + 1) / 2 <= 64) {
 		for (int c = 0; c < 2; c++) // DOWN: rows J=2,4,.. first (LSTART=2), even 1-based i first
-			relax2_pass9(so, qf, q, sor, II, JJ, down ? c : 1 - c, down, st);
+			pass9(so, qf, q, sor, II, JJ, down ? c : 1 - c, down, st, bt);
 		return;
 	}
 	const int jbF = down ? 0 : 1;
 	const int nF = (JJ - 2 - jbF + 1) / 2, nrun = (nF + frun - 1) / frun;
-	const unsigned grid = xcd_grid((unsigned)nrun);
-	if (down) hipLaunchKernelGGL((relax9_band<256, true>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun);
-	else hipLaunchKernelGGL((relax9_band<256, false>), dim3(grid), dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun);
+	const dim3 grid(xcd_grid((unsigned)nrun), bt.n);
+	if (down) hipLaunchKernelGGL((relax9_band<256, true>), grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun, bt.stride);
+	else hipLaunchKernelGGL((relax9_band<256, false>), grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun, bt.stride);
 	// S rows between runs: jbF = 0: j = 2 frun (r+1); jbF = 1: j = 1 + 2 frun (r+1), r = 0 .. nrun-2
-	launch_rows9<256>(down, so, qf, q, sor, II, JJ, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, st);
+	launch_rows9<256>(down, so, qf, q, sor, II, JJ, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, st, bt);
 }
 
 // recompute the points of column icol (0-based incl. ghost) on the rows of class jb: used after the
@@ -329,24 +341,29 @@ void relax2_fixup9(const real_t *so, const real_t *qf, real_t *q, const real_t *
 }
 
 // one colour of the five-point red-black sweep: jo in {2,3}, points with mod(i+j+jo,2) == 0 (1-based)
+static void colour5(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int jo, hipStream_t st, Batch bt)
+{
+	if (II < 3 || JJ < 3) return;
+	dim3 grid(((II - 2 + 1) / 2 + 255) / 256, JJ - 2, bt.n);
+	hipLaunchKernelGGL(relax5_colour, grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jo, bt.stride);
+}
+
 void relax2_colour5(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                     int II, int JJ, int jo, hipStream_t st)
 {
-	if (II < 3 || JJ < 3) return;
-	dim3 grid(((II - 2 + 1) / 2 + 255) / 256, JJ - 2);
-	hipLaunchKernelGGL(relax5_colour, grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jo);
+	colour5(so, qf, q, sor, II, JJ, jo, st, Batch());
 }
 
 void relax2_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-               int II, int JJ, int nstncl, int updown, hipStream_t st)
+               int II, int JJ, int nstncl, int updown, hipStream_t st, Batch bt)
 {
 	if (II < 3 || JJ < 3) return;
 	const bool down = (updown == BMG_DOWN);
 	if (nstncl == 5) {
-		relax2_sweep9(so, qf, q, sor, II, JJ, down, st);
+		relax2_sweep9(so, qf, q, sor, II, JJ, down, st, bt);
 	} else {
 		for (int c = 0; c < 2; c++)
-			relax2_colour5(so, qf, q, sor, II, JJ, down ? 2 + c : 3 - c /* LSTART..LEND */, st);
+			colour5(so, qf, q, sor, II, JJ, down ? 2 + c : 3 - c /* LSTART..LEND */, st, bt);
 	}
 }
 

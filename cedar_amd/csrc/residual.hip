@@ -18,11 +18,13 @@ namespace cedar_amd {
 template <bool NINE, bool MV = false>
 __global__ __launch_bounds__(256) void residual2_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                          const real_t *__restrict__ q, real_t *__restrict__ res,
-                                                         int II, int JJ)
+                                                         int II, int JJ, size_t bstride)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x + 1; // 0-based incl. ghost
 	const int j = blockIdx.y + 1;
 	if (i > II - 2) return;
+	if (!MV) qf += bstride * blockIdx.z; // batch item (common.h Batch)
+	q += bstride * blockIdx.z; res += bstride * blockIdx.z;
 	const size_t sj = II, PS = (size_t)II * JJ;
 	const size_t x = (size_t)i + sj * (size_t)j;
 	if (MV) {
@@ -60,26 +62,26 @@ void matvec2(const real_t *so, const real_t *q, real_t *qf, int II, int JJ, int 
 	if (II < 3 || JJ < 3) return;
 	dim3 grid((II - 2 + 255) / 256, JJ - 2);
 	if (nstncl == 5)
-		hipLaunchKernelGGL((residual2_kernel<true, true>), grid, dim3(256), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ);
+		hipLaunchKernelGGL((residual2_kernel<true, true>), grid, dim3(256), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ, (size_t)0);
 	else
-		hipLaunchKernelGGL((residual2_kernel<false, true>), grid, dim3(256), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ);
+		hipLaunchKernelGGL((residual2_kernel<false, true>), grid, dim3(256), 0, st, so, (const real_t *)nullptr, q, qf, II, JJ, (size_t)0);
 }
 
-void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st);
+void residual9_fast(const real_t *so, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, hipStream_t st, Batch bt);
 
 void residual2(const real_t *so, const real_t *qf, const real_t *q, real_t *res,
-               int II, int JJ, int nstncl, hipStream_t st)
+               int II, int JJ, int nstncl, hipStream_t st, Batch bt)
 {
 	if (II < 3 || JJ < 3) return;
 	if (nstncl == 5) { // pair-per-lane row kernel (relax2d.hip)
-		residual9_fast(so, qf, q, res, II, JJ, st);
+		residual9_fast(so, qf, q, res, II, JJ, st, bt);
 		return;
 	}
-	dim3 grid((II - 2 + 255) / 256, JJ - 2);
+	dim3 grid((II - 2 + 255) / 256, JJ - 2, bt.n);
 	if (nstncl == 5)
-		hipLaunchKernelGGL(residual2_kernel<true>, grid, dim3(256), 0, st, so, qf, q, res, II, JJ);
+		hipLaunchKernelGGL(residual2_kernel<true>, grid, dim3(256), 0, st, so, qf, q, res, II, JJ, bt.stride);
 	else
-		hipLaunchKernelGGL(residual2_kernel<false>, grid, dim3(256), 0, st, so, qf, q, res, II, JJ);
+		hipLaunchKernelGGL(residual2_kernel<false>, grid, dim3(256), 0, st, so, qf, q, res, II, JJ, bt.stride);
 }
 
 // MV: qf = A q of BMG3_SymStd_UTILS_matvec (src/3d/ftn/mpi/BMG3_SymStd_UTILS_matvec.f90:80-127)

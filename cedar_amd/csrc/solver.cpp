@@ -15,6 +15,7 @@
 #include "stage.h"
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 using namespace cedar_amd;
@@ -78,6 +79,9 @@ real_t *dalloc(size_t n)
 
 } // namespace
 
+// batch capacity of the next solver cedar_amd_solver_create builds (set by planes_setup around its call, 1 otherwise)
+static int g_create_batch = 1;
+
 struct cedar_amd_solver {
 	int nd = 2;
 	cedar_amd_settings st;
@@ -89,8 +93,15 @@ struct cedar_amd_solver {
 	// captured V-cycle
 	hipGraphExec_t gexec = nullptr;
 	const real_t *gx = nullptr, *gb = nullptr;
+	int gnb = 1; // batch count the graph was captured for
 	hipStream_t gstream = nullptr;
 	bool use_graph = true;
+	// batch of independent right-hand sides on this one hierarchy (2D, Dirichlet, V-cycle; plane relaxation runs the
+	// planes of a colour as one batch): every level's vectors hold nb_alloc items, a cycle works on the first nb
+	int nb_alloc = 1, nb = 1;
+	// a second captured cycle: the two colours of a plane sweep may differ by one plane
+	hipGraphExec_t gexec2 = nullptr;
+	int gnb2 = 0;
 	bool shared_abd = false; // ABD belongs to the solver this one was cloned from
 	// plane relaxation: side streams and their fork / join events
 	std::vector<hipStream_t> pstreams;
@@ -118,13 +129,13 @@ int compute_num_levels(int nd, len_t nx, len_t ny, len_t nz, int min_coarse)
 	return ng;
 }
 
-void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, bool lines_y, bool lines_yt)
+void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, bool lines_y, bool lines_yt, int nb = 1)
 {
 	L.nx = nx; L.ny = ny; L.nz = nd == 3 ? nz : 1;
 	L.II = nx + 2; L.JJ = ny + 2; L.KK = nd == 3 ? nz + 2 : 1;
 	L.nst = nst;
 	L.npts = (size_t)L.II * L.JJ * L.KK;
-	L.res = dalloc(L.npts);
+	L.res = dalloc(L.npts * nb);
 	L.SOR0 = dalloc(L.npts * 2);
 	if (lines_y) {
 		L.SOR1 = dalloc(L.npts * 2);
@@ -132,14 +143,14 @@ void level_init(Level &L, int nd, int nx, int ny, int nz, int nst, bool coarse, 
 	}
 	if (lines_yt) {
 		L.At = dalloc(L.npts * nst);
-		L.bt = dalloc(L.npts);
-		L.xt = dalloc(L.npts);
+		L.bt = dalloc(L.npts * nb);
+		L.xt = dalloc(L.npts * nb);
 	}
 	if (coarse) {
 		L.A = dalloc(L.npts * nst);
 		L.P = dalloc(L.npts * (nd == 3 ? 26 : 8));
-		L.x = dalloc(L.npts);
-		L.b = dalloc(L.npts);
+		L.x = dalloc(L.npts * nb);
+		L.b = dalloc(L.npts * nb);
 	}
 }
 
@@ -171,23 +182,23 @@ bool ilv_wanted(const Level &L)
 
 void residual(const cedar_amd_solver *s, const Level &L, const real_t *x, const real_t *b, real_t *r, hipStream_t st)
 {
-	if (s->nd == 2) residual2(L.A, b, x, r, L.II, L.JJ, L.nst, st);
+	if (s->nd == 2) residual2(L.A, b, x, r, L.II, L.JJ, L.nst, st, Batch{s->nb, L.npts});
 	else if (L.Ailv) residual27_op(op3_ilv(L.Ailv, L.II, L.JJ, L.KK), b, x, r, L.II, L.JJ, L.KK, st);
 	else residual3(L.A, b, x, r, L.II, L.JJ, L.KK, L.nst, st);
 }
 
 // one y-line sweep: on the transposed arrays when the level keeps them
-void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int updown, int ipn, hipStream_t st)
+void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int updown, int ipn, hipStream_t st, Batch bt = Batch())
 {
-	if (!L.At) {
+	if (!L.At) { // (batches always keep the transposed arrays: cedar_amd_solver_create)
 		relax_lines_y(L.A, b, x, sor, L.yscr, L.II, L.JJ, L.nst, updown, st, ipn);
 		return;
 	}
 	if (!L.bt_fresh) {
-		transpose2(b, L.bt, L.II, L.JJ, st);
+		transpose2(b, L.bt, L.II, L.JJ, st, bt);
 		L.bt_fresh = true;
 	}
-	relax_lines_yt(L.At, L.bt, x, L.xt, sor, L.II, L.JJ, L.nst, updown, st, L.PFy);
+	relax_lines_yt(L.At, L.bt, x, L.xt, sor, L.II, L.JJ, L.nst, updown, st, L.PFy, bt);
 }
 
 // ------------------------------------------------------------------ plane relaxation
@@ -232,14 +243,22 @@ PlaneSet *planes_setup(int dir, const real_t *so3, int II, int JJ, int KK, int n
 	plane_operator(dir, nst, so3, ps->so2, II, JJ, KK, st);
 	ps->x2s = dalloc(ps->P2 * ninst);
 	ps->b2s = dalloc(ps->P2 * ninst); // ghost entries stay zero: plane_gather writes interiors only
+	// one cycle per plane (the reference's default plane configuration): the planes of a colour run as ONE batch through
+	// the 2D kernels (common.h Batch) -- the hierarchy is shared anyway, only the vectors differ.  CEDAR_AMD_PLANE_BATCH=0,
+	// or a plane configuration with max-iter > 1 (per-plane early exit), keeps one solver instance per pair of planes.
+	const char *eb = getenv("CEDAR_AMD_PLANE_BATCH");
+	const bool want_batch = pst.max_iter == 1 && !(eb && atoi(eb) == 0);
+	g_create_batch = want_batch ? ninst : 1;
 	cedar_amd_solver *first = cedar_amd_solver_create(2, ps->I2 - 2, ps->J2 - 2, 1, nst2, ps->so2, 1, &pst);
+	g_create_batch = 1;
 	if (!first) {
 		(void)hipFree(ps->so2); (void)hipFree(ps->x2s); (void)hipFree(ps->b2s);
 		delete ps;
 		return nullptr;
 	}
 	ps->inst.push_back(first);
-	for (int q = 1; q < ninst; q++) ps->inst.push_back(clone_vectors(first));
+	if (first->nb_alloc < ninst)
+		for (int q = 1; q < ninst; q++) ps->inst.push_back(clone_vectors(first));
 	return ps;
 }
 
@@ -264,7 +283,10 @@ void planes_relax(cedar_amd_solver *s3, PlaneSet &ps, const Level &L, real_t *x,
 		if (n == 0) continue;
 		plane_gather(ps.dir, L.nst, L.A, x, b, ps.x2s, ps.b2s, L.II, L.JJ, L.KK, beg, n, st);
 		const int maxit = ps.inst[0]->st.max_iter;
-		if (maxit == 1) {
+		if (maxit == 1 && ps.inst[0]->nb_alloc >= n) { // the colour as one batch: one graph replay on the solver's stream
+			ps.inst[0]->nb = n;
+			cycle_on(ps.inst[0], ps.x2s, ps.b2s, st);
+		} else if (maxit == 1) {
 			const int S = (int)s3->pstreams.size() < n ? (int)s3->pstreams.size() : n;
 			if (S <= 1) {
 				for (int q = 0; q < n; q++) cycle_on(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q, st);
@@ -321,17 +343,18 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 			relax2_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, ipn, st);
 			continue;
 		}
+		const Batch bt{s->nb, L.npts};
 		switch (s->st.relaxation) {
-		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st); break;
-		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx); break;
-		case CEDAR_AMD_RELAX_LINE_Y: lines_y(L, x, b, L.SOR0, updown, ipn, st); break;
+		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, bt); break;
+		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx, bt); break;
+		case CEDAR_AMD_RELAX_LINE_Y: lines_y(L, x, b, L.SOR0, updown, ipn, st, bt); break;
 		default:
 			if (updown == BMG_DOWN) {
-				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx);
-				lines_y(L, x, b, L.SOR1, updown, ipn, st);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx, bt);
+				lines_y(L, x, b, L.SOR1, updown, ipn, st, bt);
 			} else {
-				lines_y(L, x, b, L.SOR1, updown, ipn, st);
-				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx);
+				lines_y(L, x, b, L.SOR1, updown, ipn, st, bt);
+				relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx, bt);
 			}
 		}
 	}
@@ -341,7 +364,7 @@ void coarse_solve(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t s
 {
 	const Level &C = s->lv.back();
 	if (s->nd == 2 && s->st.ibc) solve_cg2_per(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->st.ibc, st);
-	else if (s->nd == 2) solve_cg2(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
+	else if (s->nd == 2) solve_cg2(x, b, C.II, C.JJ, s->ABD, s->bbd, s->nabd1, s->nabd2, st, Batch{s->nb, C.npts});
 	else if (s->st.ibc) solve_cg3_per(x, b, C.II, C.JJ, C.KK, s->ABD, s->bbd, s->nabd1, s->st.ibc, st);
 	else solve_cg3(x, b, C.II, C.JJ, C.KK, s->ABD, s->bbd, s->nabd1, s->nabd2, st);
 }
@@ -353,14 +376,14 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	smooth(s, L, x, b, BMG_DOWN, s->st.nrelax_pre, st);
 	residual(s, L, x, b, L.res, st);
 	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
-	else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st, Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
 	else if (s->st.ibc) restrict3_per(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, s->st.ibc, st);
 	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
-	clear(K.x, K.npts, st); // coarse_x.set(0.0)
+	clear(K.x, K.npts * (size_t)s->nb, st); // coarse_x.set(0.0)
 	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
 	else ncycle(s, lvl + 1, K.x, K.b, st);
 	if (s->nd == 2 && s->st.ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, s->st.ibc, st);
-	else if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	else if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st, Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
 	else if (s->st.ibc) interp_add3_per(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, s->st.ibc, st);
 	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
 	smooth(s, L, x, b, BMG_UP, s->st.nrelax_post, st);
@@ -406,6 +429,18 @@ void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 	if (s->gexec && (s->gx != x || s->gb != b)) {
 		CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
 		s->gexec = nullptr;
+		if (s->gexec2) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec2));
+		s->gexec2 = nullptr;
+	}
+	if (s->gexec && s->gnb != s->nb) { // the other captured batch count (the two colours of a plane sweep)
+		if (s->gexec2 && s->gnb2 == s->nb) {
+			std::swap(s->gexec, s->gexec2);
+			std::swap(s->gnb, s->gnb2);
+		} else {
+			if (s->gexec2) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec2));
+			s->gexec2 = s->gexec; s->gnb2 = s->gnb;
+			s->gexec = nullptr;
+		}
 	}
 	if (!s->gexec) {
 		// one capture stream for the process: captures are recorded synchronously (thread-local mode), and plane
@@ -421,7 +456,7 @@ void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 		CEDAR_HIP_CHECK(hipStreamEndCapture(s->gstream, &g));
 		CEDAR_HIP_CHECK(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
 		CEDAR_HIP_CHECK(hipGraphDestroy(g));
-		s->gx = x; s->gb = b;
+		s->gx = x; s->gb = b; s->gnb = s->nb;
 	}
 	CEDAR_HIP_CHECK(hipGraphLaunch(s->gexec, st));
 }
@@ -465,6 +500,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	hipStream_t st = current_stream();
 	cedar_amd_solver *s = new cedar_amd_solver;
 	s->nd = nd;
+	s->nb_alloc = g_create_batch;
 	if (settings) s->st = *settings;
 	else cedar_amd_default_settings(&s->st);
 	const bool planes = s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY && s->st.relaxation <= CEDAR_AMD_RELAX_PLANE_XYZ;
@@ -522,7 +558,8 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	// CEDAR_AMD_YLINES_TRANSPOSED=0 keeps the gather / solve / scatter pipeline for cross-checks
 	const char *eyt = getenv("CEDAR_AMD_YLINES_TRANSPOSED");
 	const bool lyt = ly && s->st.ibc == 0 && !(eyt && atoi(eyt) == 0);
-	level_init(s->lv[0], nd, (int)nx, (int)ny, (int)nz, nstencil, false, ly, lyt);
+	if (s->nb_alloc > 1 && (nd != 2 || s->st.ibc != 0 || s->st.cycle != 0 || (ly && !lyt))) s->nb_alloc = 1; // batches: see the struct
+	level_init(s->lv[0], nd, (int)nx, (int)ny, (int)nz, nstencil, false, ly, lyt, s->nb_alloc);
 	Level &F0 = s->lv[0];
 	if (own_device_so && is_device_ptr(so)) {
 		F0.A = const_cast<real_t *>(so);
@@ -536,7 +573,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		const Level &F = s->lv[l - 1];
 		int nxc = (int)((F.nx - 1) / 2. + 1), nyc = (int)((F.ny - 1) / 2. + 1);
 		int nzc = nd == 3 ? (int)((F.nz - 1) / 2. + 1) : 1;
-		level_init(s->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, true, ly, lyt);
+		level_init(s->lv[l], nd, nxc, nyc, nzc, nd == 3 ? 14 : 5, true, ly, lyt, s->nb_alloc);
 	}
 	const Level &C = s->lv.back();
 	// periodic: the coarsest operator is stored dense (include/cedar/2d/solver.h:110-114)
@@ -558,7 +595,7 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 		}
 	}
 	s->ABD = dalloc((size_t)s->nabd1 * s->nabd2);
-	s->bbd = dalloc(s->nabd2);
+	s->bbd = dalloc((size_t)s->nabd2 * s->nb_alloc);
 	s->red = dalloc(4100);
 	CEDAR_HIP_CHECK(hipMalloc((void **)&s->dinfo, 64));
 	CEDAR_HIP_CHECK(hipMemsetAsync(s->dinfo, 0, 64, st));
@@ -643,6 +680,7 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 	if (!s) return;
 	CEDAR_HIP_CHECK(hipDeviceSynchronize());
 	if (s->gexec) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
+	if (s->gexec2) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec2));
 	for (size_t l = 0; l < s->lv.size(); l++) {
 		Level &L = s->lv[l];
 		for (int d = 0; d < 3; d++) planes_destroy(L.pl[d]);

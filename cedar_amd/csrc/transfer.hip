@@ -19,11 +19,13 @@ namespace cedar_amd {
 
 // ------------------------------------------------------------------ restrict
 __global__ __launch_bounds__(256) void restrict2_kernel(const real_t *__restrict__ q, real_t *__restrict__ qc,
-                                                         const real_t *__restrict__ ci, int II, int JJ, int IIC, int JJC)
+                                                         const real_t *__restrict__ ci, int II, int JJ, int IIC, int JJC,
+                                                         size_t bsf, size_t bsc)
 {
 	const int ic = blockIdx.x * blockDim.x + threadIdx.x + 1; // 0-based incl. ghost
 	const int jc = blockIdx.y + 1;
 	if (ic > IIC - 2) return;
+	q += bsf * blockIdx.z; qc += bsc * blockIdx.z; // batch item (common.h Batch)
 	const size_t PC = (size_t)IIC * JJC, sc = IIC, sf = II;
 	const size_t c = (size_t)ic + sc * jc;
 	const size_t f = (size_t)(2 * ic - 1) + sf * (size_t)(2 * jc - 1); // 1-based i = 2(ic1-1) -> 0-based 2*ic-1
@@ -39,11 +41,11 @@ __global__ __launch_bounds__(256) void restrict2_kernel(const real_t *__restrict
 	qc[c] = s;
 }
 
-void restrict2(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int IIC, int JJC, hipStream_t st)
+void restrict2(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int IIC, int JJC, hipStream_t st, Batch bf, Batch bc)
 {
 	if (IIC < 3 || JJC < 3) return;
-	dim3 grid((IIC - 2 + 255) / 256, JJC - 2);
-	hipLaunchKernelGGL(restrict2_kernel, grid, dim3(256), 0, st, q, qc, ci, II, JJ, IIC, JJC);
+	dim3 grid((IIC - 2 + 255) / 256, JJC - 2, bf.n);
+	hipLaunchKernelGGL(restrict2_kernel, grid, dim3(256), 0, st, q, qc, ci, II, JJ, IIC, JJC, bf.stride, bc.stride);
 }
 
 __global__ __launch_bounds__(128) void restrict3_kernel(const real_t *__restrict__ q, real_t *__restrict__ qc,
@@ -101,12 +103,14 @@ void restrict3(const real_t *q, real_t *qc, const real_t *ci, int II, int JJ, in
 __global__ __launch_bounds__(256) void interp_add2_kernel(real_t *__restrict__ q, const real_t *__restrict__ qc,
                                                            real_t *__restrict__ res, const real_t *__restrict__ so_diag,
                                                            const real_t *__restrict__ ci,
-                                                           int IIC, int JJC, int IIF, int JJF, int imax, int jmax)
+                                                           int IIC, int JJC, int IIF, int JJF, int imax, int jmax,
+                                                           size_t bsf, size_t bsc)
 {
 	// 1-based fine indices as in the reference
 	const int i = blockIdx.x * blockDim.x + threadIdx.x + 2;
 	const int j = blockIdx.y + 2;
 	if (i > IIF) return;
+	q += bsf * blockIdx.z; res += bsf * blockIdx.z; qc += bsc * blockIdx.z; // batch item (common.h Batch)
 	const size_t sf = IIF, sc = IIC, PC = (size_t)IIC * JJC;
 	const size_t x = (size_t)(i - 1) + sf * (size_t)(j - 1);
 	const bool interior = i <= IIF - 1 && j <= JJF - 1;
@@ -138,13 +142,13 @@ __global__ __launch_bounds__(256) void interp_add2_kernel(real_t *__restrict__ q
 }
 
 void interp_add2(real_t *q, const real_t *qc, real_t *res, const real_t *so, const real_t *ci,
-                 int IIC, int JJC, int IIF, int JJF, hipStream_t st)
+                 int IIC, int JJC, int IIF, int JJF, hipStream_t st, Batch bf, Batch bc)
 {
 	if (IIF < 3 || JJF < 3) return;
 	const int imax = 2 * ((IIF - 2) / 2 + 2 - 1), jmax = 2 * ((JJF - 2) / 2 + 2 - 1);
-	dim3 grid((IIF - 1 + 255) / 256, JJF - 1);
+	dim3 grid((IIF - 1 + 255) / 256, JJF - 1, bf.n);
 	hipLaunchKernelGGL(interp_add2_kernel, grid, dim3(256), 0, st, q, qc, res, so /* KO plane */, ci,
-	                   IIC, JJC, IIF, JJF, imax, jmax);
+	                   IIC, JJC, IIF, JJF, imax, jmax, bf.stride, bc.stride);
 }
 
 // ------------------------------------------------------------------ interp_add 3D

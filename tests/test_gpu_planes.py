@@ -43,6 +43,25 @@ def test_plane_sweeps_vs_oracle(K, oracle, d, nst, plane):
         assert np.max(np.abs(x1 - x2)) <= 1e-11 * np.max(np.abs(x2)), (d, nst, ud, np.max(np.abs(x1 - x2)))
 
 
+@pytest.mark.parametrize("d", ["xy", "xz", "yz"])
+@pytest.mark.parametrize("shape,nst", [((21, 18, 15), 14), ((40, 9, 12), 4), ((7, 70, 6), 14)], ids=str)
+def test_batched_planes_equal_one_solver_per_plane(K, monkeypatch, d, shape, nst):
+    """the planes of a colour as one batch through the 2D kernels (default) against one solver instance per pair of
+    planes on side streams (CEDAR_AMD_PLANE_BATCH=0): same kernels on the same data, bit-identical"""
+    nx, ny, nz = shape
+    so = varying_op(nx, ny, nz, nst, 71)
+    b, x0 = pb.uniform(so.shape[1:], 72, -1, 1), pb.uniform(so.shape[1:], 73, -1, 1)
+    out = []
+    for batch in ("1", "0"):
+        monkeypatch.setenv("CEDAR_AMD_PLANE_BATCH", batch)
+        x = x0.copy()
+        for ud in (DOWN, UP):
+            K.relax_planes3(so, x, b, d, ud)
+        out.append(x)
+    assert not np.array_equal(out[0], x0)
+    assert np.array_equal(out[0], out[1])
+
+
 def test_plane_relax_on_device_arrays(K):
     from cedar_amd import capi
     so = varying_op(12, 10, 9, 14, 5)
