@@ -144,7 +144,7 @@ void wrap3(real_t *a, int II, int JJ, int KK, int narrays, int ipn, hipStream_t 
 void wrap3_colour(real_t *q, int II, int JJ, int KK, int jb, int kb, int ipn, hipStream_t st);
 void wrap3_sweep_end(real_t *q, int II, int JJ, int KK, int ipn, hipStream_t st);
 void relax3_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int KK, int nstncl, int updown, int ipn, hipStream_t st);
+                   int II, int JJ, int KK, int nstncl, int updown, int ipn, hipStream_t st, int ghosts_consistent = 0);
 void restrict3_per(real_t *q, real_t *qc, const real_t *ci, int II, int JJ, int KK, int IIC, int JJC, int KKC, int ipn,
                    hipStream_t st);
 void interp_add3_per(real_t *q, const real_t *qc, const real_t *so, real_t *res, const real_t *ci,

@@ -324,7 +324,10 @@ __device__ __forceinline__ void load_pair27(const Op3 &A, const real_t *__restri
 // the workgroup must call it (one __syncthreads inside).
 //   EFIRST = true : colour with even 1-based i (i = 2,4,..) first  (UP order)
 //   EFIRST = false: odd i first                                     (DOWN order)
-template <int BS, bool EFIRST, bool NT, bool NTP = NT, int WI = 0>
+//   PERX: the row is periodic in x with an EVEN number of points: the ghost refresh the reference performs between and
+//   after the two colours (q(1) = q(nx+1), q(nx+2) = q(2), BMG3_SymStd_relax_GS.f90:266-269) happens here -- the last
+//   point of the second colour takes the fresh first point from LDS, and the two ghost cells are written at the end.
+template <int BS, bool EFIRST, bool NT, bool NTP = NT, int WI = 0, bool PERX = false>
 __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__restrict__ qf,
                                                  real_t *__restrict__ q, int II, size_t sj, size_t sk,
                                                  size_t j, size_t k, real_t *xch)
@@ -356,7 +359,12 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 		if (o_ok) {
 			qo[1][1][0] = e_new;
 			if (io + 1 <= II - 2) qo[1][1][2] = xch[p + 1]; // next pair's fresh e (else ghost: old value)
+			else if (PERX) qo[1][1][2] = xch[0];            // periodic: the ghost was refreshed with the row's first point
 			o_new = offdiag27(qfo, co, qo) * sro;
+		}
+		if (PERX && o_ok && io == II - 2) { // the two ghost cells: left = last point, right = first point
+			q[row] = o_new;
+			q[row + II - 1] = xch[0];
 		}
 	} else {
 		if (o_ok) {
@@ -366,8 +374,13 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 		__syncthreads();
 		if (e_ok) {
 			if (p > 0) qe[1][1][0] = xch[p]; // previous pair's fresh o (p == 0: ghost column)
+			else if (PERX) qe[1][1][0] = xch[(II - 2) / 2]; // periodic: the ghost was refreshed with the row's last point
 			if (o_ok) qe[1][1][2] = o_new;
 			e_new = offdiag27(qfe, ce, qe) * sre;
+		}
+		if (PERX && p == 0 && e_ok) {
+			q[row] = xch[(II - 2) / 2];
+			q[row + II - 1] = e_new;
 		}
 	}
 	if (e_ok) {
@@ -382,7 +395,7 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 
 // fast path: one workgroup = one grid row, both i-colours.  Rows j = j0 + jstep*jr, jr < nrj, of the
 // planes k = 1 + kb + 2*(kr + kr0), kr < nrk.
-template <int BS, bool EFIRST, bool NT>
+template <int BS, bool EFIRST, bool NT, bool PERX = false>
 __global__ __launch_bounds__(BS) void relax27_rows(const Op3 A, const real_t *__restrict__ qf,
                                                     real_t *__restrict__ q,
                                                     int II, int JJ, int KK, int j0, int jstep, int kb, int nrj, int nrk,
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(BS) void relax27_rows(const Op3 A, const real_t *__
 	if (L >= nblk || !tile_rows(L, (unsigned)nrj, (unsigned)nrk, ts, jr, kr)) return; // whole workgroup leaves together
 	const size_t j = (size_t)(j0 + jstep * (int)jr), k = (size_t)(1 + kb + 2 * ((int)kr + kr0)); // 0-based incl. ghost
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
-	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, j, k, xch);
+	relax27_row_task<BS, EFIRST, NT, NT, 0, PERX>(A, qf, q, II, sj, sk, j, k, xch);
 }
 
 // The shell of a row class (rows next to a face shared with another rank) is up to four thin rectangles of
@@ -591,6 +604,19 @@ static void launch_rows_at(bool efirst, const Op3 &A, const real_t *qf, real_t *
 		if (nt) hipLaunchKernelGGL((relax27_rows<BS, false, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
 		else hipLaunchKernelGGL((relax27_rows<BS, false, false>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, j0, jstep, kb, nrj, nrk, ts, kr0);
 	}
+}
+
+// the rows of class (jb,kb), periodic in x (even number of points per row)
+template <int BS>
+static void launch_rows_perx(bool efirst, const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, int KK, int jb, int kb,
+                             hipStream_t st)
+{
+	const int nrj = (JJ - 2 - jb + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	if (nrj <= 0 || nrk <= 0) return;
+	const TileShape ts = tile_shape_relax();
+	const unsigned grid = xcd_grid(tile_blocks((unsigned)nrj, (unsigned)nrk, ts));
+	if (efirst) hipLaunchKernelGGL((relax27_rows<BS, true, true, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, 1 + jb, 2, kb, nrj, nrk, ts, 0);
+	else hipLaunchKernelGGL((relax27_rows<BS, false, true, true>), dim3(grid), dim3(BS), 0, st, A, qf, q, II, JJ, KK, 1 + jb, 2, kb, nrj, nrk, ts, 0);
 }
 
 // the rows of class (jb,kb)
@@ -885,11 +911,37 @@ void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 // the row is done, y ghosts of a plane when the plane is done; points of one colour never read each other nor a
 // ghost refreshed under the same colour, so refreshing after the launch gives the same values), the z ghost planes
 // only once the sweep is over (:279-286) -- until then they hold the previous sweep's values, as in the reference.
+// ghosts_consistent: the caller knows that the y ghost rows of q hold the periodic image on entry (true inside the
+// cycle after the first sweep on a level; not for arrays handed in from outside) -- see the fast path below.
 void relax3_gs_per(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
-                   int II, int JJ, int KK, int nstncl, int updown, int ipn, hipStream_t st)
+                   int II, int JJ, int KK, int nstncl, int updown, int ipn, hipStream_t st, int ghosts_consistent)
 {
 	if (II < 3 || JJ < 3 || KK < 3) return;
 	const bool up = (updown == BMG_UP);
+	const bool px = ipn == 2 || ipn == 3 || ipn == 6 || ipn == 8, py = ipn == 1 || ipn == 3 || ipn == 7 || ipn == 8, pz = ipn >= 5;
+	if (nstncl == 14 && !(px && (II & 1)) && (!py || ghosts_consistent) && !(py && (JJ & 1)) && !(pz && (KK & 1))
+	    && (II - 2 + 1) / 2 <= 512) {
+		// x not periodic, even extents in the periodic directions (every level the solver relaxes on): the two i-colours of
+		// a row class run back to back in the row kernel.  The y refresh the reference performs between them copies rows
+		// 2 and ny+1, which belong to different classes when ny is even: it rewrites ghost rows with the values they
+		// already hold -- provided they held the periodic image on entry (ghosts_consistent) -- so refreshing once per
+		// class gives the same values.  The z ghosts are refreshed at the end of the sweep in either path.
+		for (int c = 0; c < 4; c++) {
+			const int cc = up ? c : 3 - c, jb = cc & 1, kb = cc >> 1;
+			if (px) { // the row kernel refreshes the x ghosts of its row itself (relax27_row_task PERX)
+				const Op3 A = op3_cedar(so, sor, II, JJ, KK);
+				const int npairs = (II - 2 + 1) / 2;
+				if (npairs <= 64) launch_rows_perx<64>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+				else if (npairs <= 128) launch_rows_perx<128>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+				else if (npairs <= 256) launch_rows_perx<256>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+				else launch_rows_perx<512>(up, A, qf, q, II, JJ, KK, jb, kb, st);
+			} else
+				relax3_pass27(so, qf, q, sor, II, JJ, KK, jb, kb, up, st);
+			wrap3_colour(q, II, JJ, KK, jb, kb, px ? (ipn == 2 ? 0 : ipn == 3 ? 1 : ipn == 6 ? 5 : 7) : ipn, st); // y only: x is done
+		}
+		wrap3_sweep_end(q, II, JJ, KK, ipn, st);
+		return;
+	}
 	if (nstncl == 14) {
 		const Op3 A = op3_cedar(so, sor, II, JJ, KK);
 		for (int c = 0; c < 8; c++) {

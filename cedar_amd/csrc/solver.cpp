@@ -330,7 +330,10 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 			continue;
 		}
 		if (s->nd == 3 && s->st.ibc) {
-			relax3_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, s->st.ibc, st);
+			// the ghosts of x hold the periodic image after any sweep, after interp_add, and on a coarse level (x starts
+			// from zero); the first pre-smoothing sweep on level 0 sees the caller's x and makes no such assumption
+			const bool consistent = it > 0 || updown == BMG_UP || &L != &s->lv[0];
+			relax3_gs_per(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, s->st.ibc, st, consistent);
 			continue;
 		}
 		if (s->nd == 3) {
