@@ -1,8 +1,9 @@
 // 3D periodic boundary conditions (ibc = 1 per_y, 2 per_x, 3 per_xy, 5 per_z, 6 per_xz, 7 per_yz, 8 per_xyz;
 // src/2d/ftn/BMG_get_bc.f90:13-20): ghost refreshes, transfers, set-up and the dense coarsest solve around
 // the Dirichlet kernels.  Replaces the periodic branches of
-//   BMG3_SymStd_relax_GS          (src/3d/ftn/BMG3_SymStd_relax_GS.f90:188-357)   colour kernels of relax3d.hip +
-//                                                                                 wrap3_colour after every colour
+//   BMG3_SymStd_relax_GS          (src/3d/ftn/BMG3_SymStd_relax_GS.f90:188-357)   relax3_gs_per (relax3d.hip): row-class
+//                                                                                 passes or one launch per colour, each
+//                                                                                 followed by wrap3_colour
 //   BMG3_SymStd_restrict          (..._restrict.f90:78-103)        ghost refresh (y, x, z), then restrict
 //   BMG3_SymStd_interp_add        (..._interp_add.f90:242-286)     interp_add, then ghost refresh
 //   BMG3_SymStd_SETUP_interp_OI   (..._SETUP_interp_OI.f90:808-2811)  the Dirichlet formulas with loops started one
