@@ -46,6 +46,17 @@ def test_host_side_of_the_cxx_mirror(tmp_path):
         assert np.array_equal(a, want), name
 
 
+def test_gpu_side_cxx_programs_compile_and_link(tmp_path):
+    """the programs the GPU tests run (kernel registry test, the reference's examples against the mirror, the plain-C
+    caller) build and link against the headers and the library here, without a GPU; the plane-config block of a
+    configuration reaches the kernel parameters"""
+    build("hip_kernels.cc", tmp_path / "hip_kernels")
+    ex = os.path.join(ROOT, "examples")
+    subprocess.run(["make", "-C", ex], check=True, capture_output=True)
+    for exe in ("ser-poisson-2d", "ser-poisson-3d", "ser-periodic-2d", "ser-periodic-3d", "capi-poisson-2d"):
+        assert os.path.exists(os.path.join(ex, exe)), exe
+
+
 @pytest.mark.gpu
 def test_registered_hip_kernels_and_user_kernels(tmp_path, oracle):
     """tests/cxx/hip_kernels.cc: the "hip" bindings with the reference's signatures against the oracle bit for bit; a
