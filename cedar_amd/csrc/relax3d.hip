@@ -859,6 +859,26 @@ void relax3_gs27_op(const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, i
 			// plane-fused: UP planes of parity 0 then 1, in a plane j-parity 0 rows first; DOWN the reverse
 			const char *ew = getenv("CEDAR_AMD_WHATIF");
 			const bool kpair = ew && atoi(ew) == 8 && npairs > 128 && npairs <= 256; // what-if: ONE launch over plane pairs
+			// experiment (bit-identical): planes in chunks -- first-parity planes [.., m], then the second-parity planes
+			// between them, and so on (a second-parity plane only needs its two first-parity neighbours done, a first-parity
+			// plane must run before its second-parity neighbours): the nine inter-plane slot planes both parities read are
+			// then a few planes apart instead of a whole sweep half, i.e. within reach of the Infinity Cache
+			const char *ec = getenv("CEDAR_AMD_KCHUNK");
+			const int kchunk = ec ? atoi(ec) : 0;
+			if (kchunk > 0 && !kpair && npairs > 128 && npairs <= 256) {
+				const int kbF = up ? 0 : 1, kbS = 1 - kbF, jbF = up ? 0 : 1;
+				const int nF = (KK - 2 - kbF + 1) / 2, nS = (KK - 2 - kbS + 1) / 2;
+				int fdone = 0;
+				for (int c0 = 0; c0 < nS; c0 += kchunk) {
+					const int hi = c0 + kchunk < nS ? c0 + kchunk : nS;
+					int needF = up ? hi + 1 : hi; // UP: S(r) lies between F(r), F(r+1); DOWN: between F(r-1), F(r)
+					if (needF > nF) needF = nF;
+					if (needF > fdone) { launch_plane<256>(up, A, qf, q, II, JJ, KK, jbF, kbF, frun, st, fdone, needF - fdone); fdone = needF; }
+					launch_plane<256>(up, A, qf, q, II, JJ, KK, jbF, kbS, frun, st, c0, hi - c0);
+				}
+				if (fdone < nF) launch_plane<256>(up, A, qf, q, II, JJ, KK, jbF, kbF, frun, st, fdone, nF - fdone);
+				return;
+			}
 			for (int c = 0; c < 2; c++) {
 				const int kb = kpair ? 1 : (up ? c : 1 - c), jbF = up ? 0 : 1;
 				if (kpair && c == 1) break;
