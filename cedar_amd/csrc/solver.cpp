@@ -79,8 +79,9 @@ real_t *dalloc(size_t n)
 
 } // namespace
 
-// batch capacity of the next solver cedar_amd_solver_create builds (set by planes_setup around its call, 1 otherwise)
-static int g_create_batch = 1;
+// cedar_amd_solver_create with a batch capacity (plane relaxation builds its 2D solvers with one: planes_setup)
+static cedar_amd_solver *solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so, int own_device_so,
+                                       const cedar_amd_settings *settings, int batch);
 
 struct cedar_amd_solver {
 	int nd = 2;
@@ -248,9 +249,7 @@ PlaneSet *planes_setup(int dir, const real_t *so3, int II, int JJ, int KK, int n
 	// or a plane configuration with max-iter > 1 (per-plane early exit), keeps one solver instance per pair of planes.
 	const char *eb = getenv("CEDAR_AMD_PLANE_BATCH");
 	const bool want_batch = pst.max_iter == 1 && !(eb && atoi(eb) == 0);
-	g_create_batch = want_batch ? ninst : 1;
-	cedar_amd_solver *first = cedar_amd_solver_create(2, ps->I2 - 2, ps->J2 - 2, 1, nst2, ps->so2, 1, &pst);
-	g_create_batch = 1;
+	cedar_amd_solver *first = solver_create(2, ps->I2 - 2, ps->J2 - 2, 1, nst2, ps->so2, 1, &pst, want_batch ? ninst : 1);
 	if (!first) {
 		(void)hipFree(ps->so2); (void)hipFree(ps->x2s); (void)hipFree(ps->b2s);
 		delete ps;
@@ -500,10 +499,18 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
                                           const real_t *so, int own_device_so,
                                           const cedar_amd_settings *settings)
 {
+	return solver_create(nd, nx, ny, nz, nstencil, so, own_device_so, settings, 1);
+}
+
+} // extern "C"
+
+static cedar_amd_solver *solver_create(int nd, len_t nx, len_t ny, len_t nz, int nstencil, const real_t *so, int own_device_so,
+                                       const cedar_amd_settings *settings, int batch)
+{
 	hipStream_t st = current_stream();
 	cedar_amd_solver *s = new cedar_amd_solver;
 	s->nd = nd;
-	s->nb_alloc = g_create_batch;
+	s->nb_alloc = batch < 1 ? 1 : batch;
 	if (settings) s->st = *settings;
 	else cedar_amd_default_settings(&s->st);
 	const bool planes = s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY && s->st.relaxation <= CEDAR_AMD_RELAX_PLANE_XYZ;
@@ -677,6 +684,8 @@ cedar_amd_solver *cedar_amd_solver_create(int nd, len_t nx, len_t ny, len_t nz, 
 	launch_check("cedar_amd_solver_create");
 	return s;
 }
+
+extern "C" {
 
 void cedar_amd_solver_destroy(cedar_amd_solver *s)
 {
