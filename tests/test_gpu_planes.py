@@ -98,6 +98,21 @@ def test_solver_with_plane_relaxation_vs_oracle(oracle, name):
     assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
 
 
+def test_f_cycle_with_plane_relaxation_vs_oracle(oracle):
+    from cedar_amd import capi
+    so = pb.diag_diffusion3(20, 18, 17, 1.0, 1.0, 1e-3)
+    b = pb.rhs3(20, 18, 17)
+    s = capi.Solver(so, relax="plane-xy", cycle="f", max_iter=4)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    ml = oracle.ml_create(so, relax="plane-xy", cycle="f")
+    xo = np.zeros_like(b)
+    ho = ml.solve(b, xo, maxiter=4, tol=1e-8)
+    ml.close()
+    assert len(h) == len(ho)
+    np.testing.assert_allclose(h, ho, rtol=1e-8, atol=1e-13)
+
+
 def test_plane_relaxation_refusals(capfd):
     from cedar_amd import capi
     s = capi.Solver(pb.poisson2(20, 20), relax="plane-xy")  # 2D: falls back to point relaxation, loudly
