@@ -298,10 +298,15 @@ class GpuBackend:
     def relax_colour7(self, A, b, x, sor, pts):
         self.lib.cedar_amd_relax3_colour7(self._p(A), self._p(b), self._p(x), self._p(sor), *self._dims(x), pts)
 
-    def recip(self, A, sor):
+    def recip(self, A, sor, solve_copy=False):
         self.lib.BMG3_SymStd_SETUP_recip(self._p(A), self._p(sor), *self._dims(sor), A.shape[0], 2)
-        # cedar_amd_relax3_prepare (row-interleaved solve copy for the per-piece entry points) is not called here: on
-        # the rank-grid paths it measured neutral (512^3 per rank, profiles/r02_dist_orchestration_cost.log)
+        # solve_copy: register a row-interleaved solve copy of a 27-point level for the per-piece entry points
+        # (cedar_amd_relax3_prepare; dropped when A is released through cedar_amd_free).  Only the slab decomposition
+        # asks for it: its sweeps are the plane-fused passes of the single-GPU solver, where the copy is worth 7 %; on
+        # rank grids with an x / y split (four row-class launches) it measured neutral
+        # (profiles/r02_dist_orchestration_cost.log)
+        if solve_copy and A.shape[0] == 14 and hasattr(A, "ptr"):
+            self.lib.cedar_amd_relax3_prepare(self._p(A), self._p(sor), *self._dims(sor))
 
     def residual(self, A, x, b, r):
         nst = A.shape[0]
@@ -420,7 +425,10 @@ class DistSolver3:
                 K.halo.exchange(K.P)
             be.galerkin(F.A, K.A, K.P)
             K.halo.exchange(K.A)
-            be.recip(F.A, F.sor)
+            if isinstance(be, GpuBackend):
+                be.recip(F.A, F.sor, solve_copy=(t.p[0] == 1 and t.p[1] == 1))
+            else:
+                be.recip(F.A, F.sor)
         # level la: assemble the global operator on every rank; the single-domain solver takes over
         Cl = self.levels[-1]
         self.cn = Cl.n
