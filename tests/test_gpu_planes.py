@@ -100,6 +100,26 @@ def test_solver_with_plane_relaxation_vs_oracle(oracle, name):
     assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
 
 
+@pytest.mark.parametrize("shape,nst", [((9, 8, 7), 14), ((7, 7, 7), 4), ((6, 9, 13), 14), ((16, 5, 9), 4), ((5, 17, 6), 14)], ids=str)
+def test_small_and_ragged_grids_with_plane_relaxation(oracle, shape, nst):
+    """odd / tiny extents: planes whose 2D solver has one or two levels, colours of unequal size, batches of one plane"""
+    from cedar_amd import capi
+    nx, ny, nz = shape
+    so = varying_op(nx, ny, nz, nst, 91)
+    b = pb.uniform(so.shape[1:], 92, -1, 1) * pb.interior_mask(so.shape[1:])
+    s = capi.Solver(so, relax="plane-xyz", max_iter=4)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    ml = oracle.ml_create(so, relax="plane-xyz")
+    assert s.nlevels() == ml.nlevels()
+    xo = np.zeros_like(b)
+    ho = ml.solve(b, xo, maxiter=4, tol=1e-8)
+    ml.close()
+    assert len(h) == len(ho)
+    np.testing.assert_allclose(h, ho, rtol=1e-8, atol=1e-13)
+    assert np.max(np.abs(x - xo)) <= 1e-10 * max(np.max(np.abs(xo)), 1e-300)
+
+
 def test_f_cycle_with_plane_relaxation_vs_oracle(oracle):
     from cedar_amd import capi
     so = pb.diag_diffusion3(20, 18, 17, 1.0, 1.0, 1e-3)
