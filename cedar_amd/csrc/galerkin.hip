@@ -211,10 +211,12 @@ void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF
 		// is superseded by the per-COARSE-point row sums below.)
 		const char *e3 = getenv("CEDAR_AMD_GALERKIN_TILED");
 		if (e3 && atoi(e3) == 1 && galerkin3_tiled(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
-		// 27-point fine operator: row sums per coarse point, then the contraction (galerkin3_rows.hip; 512^3: 55 -> 28 ms);
-		// CEDAR_AMD_GALERKIN_ROWS=0 keeps the one-stage launch, =1 forces the row sums for a 7-point operator too
+		// row sums per coarse point, then the contraction (galerkin3_rows.hip; 512^3, 27-point: 55 -> 18 ms): for a 27-point
+		// fine operator always, for a 7-point one where the operator can be read as aligned pairs (13.7 -> 12.1 ms; with
+		// 8-byte loads the one-stage launch is as fast).  CEDAR_AMD_GALERKIN_ROWS=0 keeps the one-stage launch, =1 forces
+		// the row sums
 		const char *e1 = getenv("CEDAR_AMD_GALERKIN_ROWS");
-		const bool rows = e1 ? atoi(e1) == 1 : ifd != 1;
+		const bool rows = e1 ? atoi(e1) == 1 : (ifd != 1 || galerkin3_rows_pairs(so, IIF));
 		if (rows && galerkin3_rows(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, ifd, st)) return;
 		if (ifd == 1) galerkin3_fused7(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, st);
 		else galerkin3_fused27(so, soc, ci, IIF, JJF, KKF, IIC, JJC, KKC, st);

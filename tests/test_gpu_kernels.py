@@ -234,11 +234,13 @@ def test_unserved_boundary_codes_are_refused_loudly(K, capfd):
 
 
 @pytest.mark.parametrize("shape,nst", [((9, 8, 7), 14), ((13, 9, 10), 4), ((33, 20, 17), 14), ((17, 12, 31), 4), ((3, 4, 5), 14),
-                                       ((130, 6, 9), 14)], ids=str)
+                                       ((130, 6, 9), 14), ((8, 8, 8), 14), ((10, 7, 9), 4), ((34, 21, 16), 14), ((4, 4, 4), 14),
+                                       ((6, 5, 4), 4), ((258, 6, 7), 14), ((132, 9, 6), 4)], ids=str)
 def test_row_sum_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeypatch, shape, nst):
     """the row-sum product (galerkin3_rows.hip, the default for 27-point fine operators) keeps the one-stage kernels'
-    summation order: same coarse operator bit for bit, with the whole grid in one slab and with slabs of 1 and 3
-    coarse planes (ring of row-sum planes)"""
+    summation order: same coarse operator bit for bit (signs of zeros included), with the whole grid in one slab and
+    with slabs of 1 and 3 coarse planes (ring of row-sum planes); an even nx takes the paired operator loads
+    (row_group, with the terms outside the grid dropped by a select), CEDAR_AMD_GALERKIN_PAIRS=0 the 8-byte loads"""
     import problems as pb
     nx, ny, nz = shape
     g = (nz + 2, ny + 2, nx + 2)
@@ -246,15 +248,16 @@ def test_row_sum_galerkin_is_bit_identical_to_the_one_stage_kernels(K, monkeypat
     so = pb.random_op(g, nst, 5, zero_ghost=False)
     ci = pb.uniform((26,) + gc, 6, -1, 1)
     out = []
-    for rows, slab in (("0", "32"), ("1", "1000"), ("1", "1"), ("1", "3")):
+    for rows, slab, pairs in (("0", "32", "1"), ("1", "1000", "1"), ("1", "1", "1"), ("1", "3", "1"), ("1", "3", "0")):
         monkeypatch.setenv("CEDAR_AMD_GALERKIN_ROWS", rows)
         monkeypatch.setenv("CEDAR_AMD_GALERKIN_SLAB", slab)
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_PAIRS", pairs)
         soc = np.zeros((14,) + gc)
         K.galerkin3(so, soc, ci)
         out.append(soc)
     assert np.any(out[0] != 0)
     for o in out[1:]:
-        assert np.array_equal(out[0], o)
+        assert np.array_equal(out[0].view(np.int64), o.view(np.int64))
 
 
 def _random_cases(nd, count, seed, lo, hi):
