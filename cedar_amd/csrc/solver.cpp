@@ -429,6 +429,7 @@ void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 		return;
 	}
 	if (s->gexec && (s->gx != x || s->gb != b)) {
+		CEDAR_HIP_CHECK(hipStreamSynchronize(st)); // a replay of the old graph may still be running
 		CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
 		s->gexec = nullptr;
 		if (s->gexec2) CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec2));
