@@ -6,7 +6,10 @@ the oracle; parity there goes through size-independent properties, all on device
   * the plane-fused 27-pt pass equals the four-launch order bit for bit;
   * contraction: one V(2,1) cycle from x = 0 reduces the error x* - x by the factor multigrid
     promises (< 0.2), and ten cycles reach the rounding floor;
-  * the cycle is deterministic (two runs agree bit for bit).
+  * the cycle is deterministic (two runs agree bit for bit);
+  * set-up: the row-sum Galerkin product (paired operator loads, slabs of 32 coarse planes) equals the one-stage
+    kernels bit for bit, and the coarse operator is variational: A_c v = R (A (P v)) to rounding for a coarse field v,
+    with P, R and A applied by the cycle's own kernels.
 """
 import numpy as np
 import pytest
@@ -101,6 +104,49 @@ def test_27pt_512_cubed(capi, monkeypatch):
         s.vcycle(xa, b)
     assert rel_err(xa.numpy(), xs_h) <= 1e-9
     s.close()
+
+
+def test_27pt_512_cubed_setup(capi, monkeypatch):
+    n = 512
+    K = capi.Kernels()
+    so, _ = capi.gallery("fe3", (n, n, n), with_rhs=False)
+    g = (n + 2,) * 3
+    gc = pb.coarse_shape(g)
+    ci = capi.DeviceArray((26,) + gc)
+    ci.zero()
+    K.setup_interp3(so, ci)
+    out = []
+    for rows in ("1", "0"):
+        monkeypatch.setenv("CEDAR_AMD_GALERKIN_ROWS", rows)
+        soc = capi.DeviceArray((14,) + gc)
+        soc.zero()
+        K.galerkin3(so, soc, ci)
+        out.append(soc)
+    monkeypatch.delenv("CEDAR_AMD_GALERKIN_ROWS")
+    h = out[0].numpy()
+    assert np.any(h[0] != 0)
+    assert np.array_equal(h.view(np.int64), out[1].numpy().view(np.int64)), "row-sum product differs from the one-stage kernels"
+    del h
+    out[1].free()
+    soc = out[0]
+    # variational property with the cycle's own transfer kernels
+    vc_h = smooth_field(gc)
+    vc = capi.DeviceArray.from_numpy(vc_h)
+    pf, zero = capi.DeviceArray(g), capi.DeviceArray(g)
+    pf.zero()
+    zero.zero()
+    K.interp_add3(pf, vc, so, zero, ci)        # pf = P vc (the residual term of interp_add is zero)
+    af = capi.DeviceArray(g)
+    K.matvec3(so, pf, af)                      # A (P vc)
+    rc = capi.DeviceArray(gc)
+    rc.zero()
+    K.restrict3(af, rc, ci)                    # R A P vc
+    ac = capi.DeviceArray(gc)
+    K.matvec3(soc, vc, ac)                     # A_c vc
+    rc_h, ac_h = rc.numpy()[1:-1, 1:-1, 1:-1], ac.numpy()[1:-1, 1:-1, 1:-1]
+    scale = 27.0 * float(np.max(np.abs(soc.numpy()[0]))) * float(np.max(np.abs(vc_h)))
+    assert float(np.max(np.abs(ac_h))) > 1e-6 * scale
+    assert float(np.max(np.abs(rc_h - ac_h))) <= 1e-13 * scale
 
 
 @pytest.mark.parametrize("wl", ["2d9", "2d9l"])
