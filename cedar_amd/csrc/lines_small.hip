@@ -1,0 +1,140 @@
+// Zebra line relaxation on a small 2D level, all sweeps of one visit in ONE launch
+// (BMG2_SymStd_relax_lines_x.f90:75-176, relax_lines_y.f90:77-176; multilevel.h:179-218 for the order of the two
+// directions).
+//
+// On a level of at most 64 x 64 unknowns a sweep of relax_lines_x / relax_lines_yt is latency: two colour launches per
+// direction plus the two transposes of a y sweep (and one of the right-hand side per visit), ~7 us each with a few
+// hundred points of work -- a line-xy V(2,1) visit is some twenty launches.  Plane relaxation runs one such 2D cycle
+// per plane colour and 3D level, so its V-cycle was bound by these launches (profiles/r02_plane_relaxation_vcycle.log:
+// 1900 kernels of ~7 us per cycle at 256^3).
+// Here one workgroup owns the level (one per batch item): the unknowns sit in LDS for the whole visit; per colour the
+// right-hand sides of its lines are formed by all lanes (reference term order), the factors of those lines are staged
+// beside them, and each line is solved by ONE lane sequentially -- DPTTRS's own order, so a line solve is the
+// reference's to the bit where the scan of the big-level kernels re-associates.
+#include "common.h"
+
+namespace cedar_amd {
+
+namespace {
+constexpr int SMALL_MAX = 64; // unknowns per direction
+constexpr int LP = 33;        // lines of one colour (<= 32) + 1: conflict-free [unknown][line] layout
+
+// kind: 1 = x lines, 2 = y lines, 3 = both (DOWN: x then y, UP: y then x)
+template <bool NINE>
+__global__ __launch_bounds__(256) void lines_small_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                          real_t *__restrict__ q, const real_t *__restrict__ sorx,
+                                                          const real_t *__restrict__ sory, int II, int JJ, int kind,
+                                                          int updown, int nsweeps, size_t bstride)
+{
+	extern __shared__ __attribute__((aligned(16))) real_t lds[];
+	const int PSi = II * JJ;
+	real_t *qs = lds, *ys = qs + PSi, *dsv = ys + SMALL_MAX * LP, *esv = dsv + SMALL_MAX * LP;
+	qf += bstride * blockIdx.x; q += bstride * blockIdx.x; // batch item (common.h Batch)
+	const int tid = threadIdx.x, NT = blockDim.x;
+	const size_t PS = (size_t)PSi;
+	for (int x = tid; x < PSi; x += NT) qs[x] = q[x];
+	__syncthreads();
+	const int nsteps = kind == 3 ? 4 : 2;
+	for (int sw = 0; sw < nsweeps; sw++) {
+		for (int step = 0; step < nsteps; step++) {
+			const bool xdir = kind == 1 || (kind == 3 && ((updown == BMG_DOWN) == (step < 2)));
+			const int c = step & 1;
+			const int cb = (updown == BMG_DOWN) ? 1 - c : c; // DOWN: lines 3, 5, .. (1-based) first
+			const int n = xdir ? II - 2 : JJ - 2;
+			const int nlines = ((xdir ? JJ : II) - 2 - cb + 1) / 2;
+			if (nlines <= 0) continue; // uniform
+			// right-hand sides and factors of the colour's lines
+			for (int idx = tid; idx < nlines * n; idx += NT) {
+				int t, l, i, j;
+				if (xdir) { t = idx % n; l = idx / n; i = t + 1; j = 1 + cb + 2 * l; }
+				else { l = idx % nlines; t = idx / nlines; i = 1 + cb + 2 * l; j = t + 1; }
+				const int x = i + II * j;
+				real_t s = qf[x];
+				if (xdir) { // relax_lines_x.f90:106-111
+					s = s + so[KS * PS + x] * qs[x - II];
+					s = s + so[KS * PS + x + II] * qs[x + II];
+					if (NINE) {
+						s = s + so[KSW * PS + x] * qs[x - 1 - II];
+						s = s + so[KNW * PS + x + 1] * qs[x + 1 - II];
+						s = s + so[KNW * PS + x + II] * qs[x - 1 + II];
+						s = s + so[KSW * PS + x + 1 + II] * qs[x + 1 + II];
+					}
+					dsv[t * LP + l] = sorx[(size_t)II * j + 1 + t];
+					esv[t * LP + l] = t < n - 1 ? sorx[PS + (size_t)II * j + 2 + t] : 0.0;
+				} else { // relax_lines_y.f90:103-107
+					s = s + so[KW * PS + x] * qs[x - 1];
+					s = s + so[KW * PS + x + 1] * qs[x + 1];
+					if (NINE) {
+						s = s + so[KSW * PS + x] * qs[x - 1 - II];
+						s = s + so[KNW * PS + x + 1] * qs[x + 1 - II];
+						s = s + so[KNW * PS + x + II] * qs[x - 1 + II];
+						s = s + so[KSW * PS + x + 1 + II] * qs[x + 1 + II];
+					}
+					dsv[t * LP + l] = sory[(size_t)JJ * i + 1 + t]; // SOR(JJ,II,2)
+					esv[t * LP + l] = t < n - 1 ? sory[PS + (size_t)JJ * i + 2 + t] : 0.0;
+				}
+				ys[t * LP + l] = s;
+			}
+			__syncthreads();
+			// DPTTRS per line: y_t = y_t - e_{t-1} y_{t-1};  x_n = y_n / d_n, x_t = y_t / d_t - e_t x_{t+1}
+			if (tid < nlines) {
+				const int l = tid;
+				real_t v = ys[l];
+#pragma unroll 8
+				for (int t = 1; t < n; t++) {
+					v = (-esv[(t - 1) * LP + l]) * v + ys[t * LP + l];
+					ys[t * LP + l] = v;
+				}
+				v = ys[(n - 1) * LP + l] / dsv[(n - 1) * LP + l];
+				ys[(n - 1) * LP + l] = v;
+#pragma unroll 8
+				for (int t = n - 2; t >= 0; t--) {
+					v = (-esv[t * LP + l]) * v + ys[t * LP + l] / dsv[t * LP + l];
+					ys[t * LP + l] = v;
+				}
+			}
+			__syncthreads();
+			for (int idx = tid; idx < nlines * n; idx += NT) {
+				int t, l, i, j;
+				if (xdir) { t = idx % n; l = idx / n; i = t + 1; j = 1 + cb + 2 * l; }
+				else { l = idx % nlines; t = idx / nlines; i = 1 + cb + 2 * l; j = t + 1; }
+				qs[i + II * j] = ys[t * LP + l];
+			}
+			__syncthreads();
+		}
+	}
+	for (int idx = tid; idx < (II - 2) * (JJ - 2); idx += NT) {
+		const int x = 1 + idx % (II - 2) + II * (1 + idx / (II - 2));
+		q[x] = qs[x];
+	}
+}
+} // namespace
+
+// Dirichlet levels of at most 64 x 64 unknowns (CEDAR_AMD_LINES_SMALL=0: the per-colour kernels everywhere)
+bool lines_small_ok(int II, int JJ)
+{
+	static const bool off = getenv("CEDAR_AMD_LINES_SMALL") && atoi(getenv("CEDAR_AMD_LINES_SMALL")) == 0;
+	return !off && II >= 3 && JJ >= 3 && II - 2 <= SMALL_MAX && JJ - 2 <= SMALL_MAX;
+}
+
+// kind: 1 = x lines (sorx), 2 = y lines (sory), 3 = line-xy; nsweeps sweeps in the direction `updown`
+void relax_lines_small(const real_t *so, const real_t *qf, real_t *q, const real_t *sorx, const real_t *sory,
+                       int II, int JJ, int nstncl, int kind, int updown, int nsweeps, hipStream_t st, Batch bt)
+{
+	if (nsweeps <= 0) return;
+	const size_t shm = ((size_t)II * JJ + 3 * (size_t)SMALL_MAX * LP) * sizeof(real_t);
+	static bool attr = false;
+	if (!attr) { // 86 KB for a 66 x 66 level
+		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)lines_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)lines_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		attr = true;
+	}
+	if (nstncl == 5)
+		hipLaunchKernelGGL(lines_small_kernel<true>, dim3(bt.n), dim3(256), shm, st, so, qf, q, sorx, sory, II, JJ, kind, updown,
+		                   nsweeps, bt.stride);
+	else
+		hipLaunchKernelGGL(lines_small_kernel<false>, dim3(bt.n), dim3(256), shm, st, so, qf, q, sorx, sory, II, JJ, kind, updown,
+		                   nsweeps, bt.stride);
+}
+
+} // namespace cedar_amd

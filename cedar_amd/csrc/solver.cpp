@@ -319,6 +319,13 @@ void planes_relax(cedar_amd_solver *s3, PlaneSet &ps, const Level &L, real_t *x,
 
 void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *b, int updown, int n, hipStream_t st)
 {
+	if (s->nd == 2 && s->st.ibc == 0 && s->st.relaxation >= CEDAR_AMD_RELAX_LINE_X && s->st.relaxation <= CEDAR_AMD_RELAX_LINE_XY
+	    && lines_small_ok(L.II, L.JJ)) {
+		// a small level: every sweep of this visit in one launch, the level resident in LDS (lines_small.hip)
+		const int kind = s->st.relaxation == CEDAR_AMD_RELAX_LINE_X ? 1 : s->st.relaxation == CEDAR_AMD_RELAX_LINE_Y ? 2 : 3;
+		relax_lines_small(L.A, b, x, L.SOR0, kind == 2 ? L.SOR0 : L.SOR1, L.II, L.JJ, L.nst, kind, updown, n, st, Batch{s->nb, L.npts});
+		return;
+	}
 	for (int it = 0; it < n; it++) {
 		if (s->nd == 3 && s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY) { // multilevel.h:179-189, :208-218
 			static const int down[3] = {0, 2, 1}, up[3] = {1, 2, 0}; // xy, yz, xz on the way down; xz, yz, xy on the way up
