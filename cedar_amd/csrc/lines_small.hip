@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void lines_small_kernel(const real_t *__restri
 // Dirichlet levels of at most 64 x 64 unknowns (CEDAR_AMD_LINES_SMALL=0: the per-colour kernels everywhere)
 bool lines_small_ok(int II, int JJ)
 {
-	static const bool off = getenv("CEDAR_AMD_LINES_SMALL") && atoi(getenv("CEDAR_AMD_LINES_SMALL")) == 0;
+	const char *e = getenv("CEDAR_AMD_LINES_SMALL"); // read per call: a solver records its choice in its cycle graph
+	const bool off = e && atoi(e) == 0;
 	return !off && II >= 3 && JJ >= 3 && II - 2 <= SMALL_MAX && JJ - 2 <= SMALL_MAX;
 }
 

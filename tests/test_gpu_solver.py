@@ -156,3 +156,33 @@ def test_y_lines_on_transposed_arrays_match_the_gather_pipeline(capi, monkeypatc
     d = np.argwhere(out["0"][1] != out["1"][1])
     assert len(d) == 0, (len(d), d[:6].tolist(), [(float(out["0"][1][tuple(i)]), float(out["1"][1][tuple(i)])) for i in d[:6]])
     assert np.array_equal(out["0"][0], out["1"][0])
+
+
+@pytest.mark.parametrize("shape,relax,op,cycle", [((64, 64), "line-xy", "aniso9", "v"), ((40, 33), "line-xy", "stretch5", "v"),
+                                                  ((17, 64), "line-x", "aniso9", "v"), ((63, 9), "line-y", "aniso9", "v"),
+                                                  ((130, 77), "line-xy", "aniso9", "v"), ((96, 130), "line-xy", "aniso9", "f"),
+                                                  ((3, 5), "line-xy", "aniso9", "v")], ids=str)
+def test_small_level_line_sweeps_match_the_per_colour_kernels(capi, oracle, monkeypatch, shape, relax, op, cycle):
+    """levels of at most 64 x 64 unknowns run every line sweep of a visit in one launch with one lane per line solve
+    (lines_small.hip, DPTTRS's order); the per-colour kernels (CEDAR_AMD_LINES_SMALL=0) solve the same lines with a
+    scan: same iterates up to the association of the line solves, and both follow the oracle's history"""
+    nx, ny = shape
+    so = pb.aniso9(nx, ny) if op == "aniso9" else pb.diag_diffusion2(nx, ny, 1e-2, 1.0)
+    b = pb.rhs2(nx, ny)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CEDAR_AMD_LINES_SMALL", flag)
+        s = capi.Solver(so, relax=relax, nrelax_pre=2, nrelax_post=1, cycle=cycle)
+        x = np.zeros_like(b)
+        h = s.solve(b, x)
+        s.close()
+        out[flag] = (np.array(h), x)
+    ml = oracle.ml_create(so, relax=relax, cycle=cycle)
+    xo = np.zeros_like(b)
+    ho = np.array(ml.solve(b, xo))
+    ml.close()
+    for flag in ("0", "1"):
+        assert len(out[flag][0]) == len(ho)
+        np.testing.assert_allclose(out[flag][0], ho, rtol=1e-10, atol=1e-12)
+        assert np.max(np.abs(out[flag][1] - xo)) <= 1e-10 * np.max(np.abs(xo))
+    assert np.max(np.abs(out["0"][1] - out["1"][1])) <= 1e-11 * np.max(np.abs(xo))
