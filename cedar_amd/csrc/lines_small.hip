@@ -21,7 +21,7 @@ constexpr int LP = 33;        // lines of one colour (<= 32) + 1: conflict-free 
 
 // kind: 1 = x lines, 2 = y lines, 3 = both (DOWN: x then y, UP: y then x)
 template <bool NINE>
-__global__ __launch_bounds__(256) void lines_small_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+__global__ __launch_bounds__(1024) void lines_small_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                           real_t *__restrict__ q, const real_t *__restrict__ sorx,
                                                           const real_t *__restrict__ sory, int II, int JJ, int kind,
                                                           int updown, int nsweeps, size_t bstride)
@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void lines_small_kernel(const real_t *__restri
 				ys[t * LP + l] = s;
 			}
 			__syncthreads();
-			// DPTTRS per line: y_t = y_t - e_{t-1} y_{t-1};  x_n = y_n / d_n, x_t = y_t / d_t - e_t x_{t+1}
+			// DPTTRS per line: y_t = y_t - e_{t-1} y_{t-1};  x_n = y_n / d_n, x_t = y_t / d_t - e_t x_{t+1}.
+			// The two recurrences run on one lane per line; the divisions between them do not depend on the recurrence
+			// and are done by all lanes (a double division is ~30 instructions: in the chain it was most of the kernel)
 			if (tid < nlines) {
 				const int l = tid;
 				real_t v = ys[l];
@@ -85,11 +87,19 @@ __global__ __launch_bounds__(256) void lines_small_kernel(const real_t *__restri
 					v = (-esv[(t - 1) * LP + l]) * v + ys[t * LP + l];
 					ys[t * LP + l] = v;
 				}
-				v = ys[(n - 1) * LP + l] / dsv[(n - 1) * LP + l];
-				ys[(n - 1) * LP + l] = v;
+			}
+			__syncthreads();
+			for (int idx = tid; idx < nlines * n; idx += NT) {
+				const int l = idx % nlines, t = idx / nlines;
+				ys[t * LP + l] = ys[t * LP + l] / dsv[t * LP + l];
+			}
+			__syncthreads();
+			if (tid < nlines) {
+				const int l = tid;
+				real_t v = ys[(n - 1) * LP + l];
 #pragma unroll 8
 				for (int t = n - 2; t >= 0; t--) {
-					v = (-esv[t * LP + l]) * v + ys[t * LP + l] / dsv[t * LP + l];
+					v = (-esv[t * LP + l]) * v + ys[t * LP + l];
 					ys[t * LP + l] = v;
 				}
 			}
@@ -130,11 +140,14 @@ void relax_lines_small(const real_t *so, const real_t *qf, real_t *q, const real
 		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)lines_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 		attr = true;
 	}
+	// lanes for the right-hand sides: up to 32 lines x 64 unknowns per colour
+	const int work = ((II > JJ ? II : JJ) - 2) * (((II < JJ ? II : JJ) - 2 + 1) / 2);
+	const int nthr = work > 512 ? 1024 : work > 256 ? 512 : 256;
 	if (nstncl == 5)
-		hipLaunchKernelGGL(lines_small_kernel<true>, dim3(bt.n), dim3(256), shm, st, so, qf, q, sorx, sory, II, JJ, kind, updown,
+		hipLaunchKernelGGL(lines_small_kernel<true>, dim3(bt.n), dim3(nthr), shm, st, so, qf, q, sorx, sory, II, JJ, kind, updown,
 		                   nsweeps, bt.stride);
 	else
-		hipLaunchKernelGGL(lines_small_kernel<false>, dim3(bt.n), dim3(256), shm, st, so, qf, q, sorx, sory, II, JJ, kind, updown,
+		hipLaunchKernelGGL(lines_small_kernel<false>, dim3(bt.n), dim3(nthr), shm, st, so, qf, q, sorx, sory, II, JJ, kind, updown,
 		                   nsweeps, bt.stride);
 }
 
