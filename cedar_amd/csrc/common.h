@@ -218,6 +218,8 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st, Batch bt = Batch());
 // lines_small.hip: all line sweeps of one visit of a level of at most 64 x 64 unknowns in one launch
 bool lines_small_ok(int II, int JJ);
+void relax_points_small(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int nstncl,
+                        int updown, int nsweeps, hipStream_t st, Batch bt = Batch());
 void relax_lines_small(const real_t *so, const real_t *qf, real_t *q, const real_t *sorx, const real_t *sory,
                        int II, int JJ, int nstncl, int kind, int updown, int nsweeps, hipStream_t st, Batch bt = Batch());
 void setup_lines_yt(const real_t *so, real_t *sot, int II, int JJ, int nstncl, hipStream_t st);

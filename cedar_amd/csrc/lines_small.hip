@@ -1,4 +1,4 @@
-// Zebra line relaxation on a small 2D level, all sweeps of one visit in ONE launch
+// Relaxation on a small 2D level, all sweeps of one visit in ONE launch: zebra lines, and point Gauss-Seidel below
 // (BMG2_SymStd_relax_lines_x.f90:75-176, relax_lines_y.f90:77-176; multilevel.h:179-218 for the order of the two
 // directions).
 //
@@ -119,6 +119,87 @@ __global__ __launch_bounds__(1024) void lines_small_kernel(const real_t *__restr
 	}
 }
 } // namespace
+
+namespace {
+// Point Gauss-Seidel on such a level (BMG2_SymStd_relax_GS.f90:80-135): the colours of every sweep of the visit in one
+// launch.  Same expression per point as relax9_rows / relax5_colour (gs9_mem's term order, times the stored
+// reciprocal), and a colour's points do not read one another: bit-identical to the per-colour launches.
+template <bool NINE>
+__global__ __launch_bounds__(1024) void points_small_kernel(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                            real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                            int II, int JJ, int updown, int nsweeps, size_t bstride)
+{
+	extern __shared__ __attribute__((aligned(16))) real_t lds[];
+	const int PSi = II * JJ;
+	real_t *qs = lds;
+	qf += bstride * blockIdx.x; q += bstride * blockIdx.x;
+	const int tid = threadIdx.x, NT = blockDim.x;
+	const size_t PS = (size_t)PSi;
+	const bool down = updown == BMG_DOWN;
+	for (int x = tid; x < PSi; x += NT) qs[x] = q[x];
+	__syncthreads();
+	const int nxh = (II - 2 + 1) / 2; // points of one i-parity per row, at most
+	for (int sw = 0; sw < nsweeps; sw++) {
+		for (int step = 0; step < (NINE ? 4 : 2); step++) {
+			if (NINE) {
+				// relax2_sweep9: row class jb = c (DOWN) / 1-c (UP), c = 0, 1; in a row the even 1-based i first on the
+				// way down (0-based offset ie = 2p+1), the odd ones first on the way up
+				const int c = step >> 1, jb = down ? c : 1 - c;
+				const int ib = (down == ((step & 1) == 0)) ? 1 : 2; // 0-based first point of the i-colour
+				const int nrows = (JJ - 2 - jb + 1) / 2;
+				for (int idx = tid; idx < nrows * nxh; idx += NT) {
+					const int i = ib + 2 * (idx % nxh), j = 1 + jb + 2 * (idx / nxh);
+					if (i > II - 2) continue;
+					const int x = i + II * j;
+					real_t s = qf[x];
+					s = s + so[KW * PS + x] * qs[x - 1];
+					s = s + so[KW * PS + x + 1] * qs[x + 1];
+					s = s + so[KS * PS + x] * qs[x - II];
+					s = s + so[KS * PS + x + II] * qs[x + II];
+					s = s + so[KSW * PS + x] * qs[x - 1 - II];
+					s = s + so[KNW * PS + x + 1] * qs[x + 1 - II];
+					s = s + so[KNW * PS + x + II] * qs[x - 1 + II];
+					s = s + so[KSW * PS + x + 1 + II] * qs[x + 1 + II];
+					qs[x] = s * sor[PS + x];
+				}
+			} else {
+				// relax2_gs: colours LSTART..LEND = 2, 3 on the way down, 3, 2 on the way up; colour jo holds the points
+				// i1 = mod(j1 + jo, 2) + 2 + 2a of the rows j1 = 2 .. JJ-1 (1-based)
+				const int jo = down ? 2 + step : 3 - step;
+				for (int idx = tid; idx < (JJ - 2) * nxh; idx += NT) {
+					const int j1 = 2 + idx / nxh, i1 = (j1 + jo) % 2 + 2 + 2 * (idx % nxh);
+					if (i1 > II - 1) continue;
+					const int x = (i1 - 1) + II * (j1 - 1);
+					real_t s = qf[x];
+					s = s + so[KW * PS + x] * qs[x - 1];
+					s = s + so[KW * PS + x + 1] * qs[x + 1];
+					s = s + so[KS * PS + x] * qs[x - II];
+					s = s + so[KS * PS + x + II] * qs[x + II];
+					qs[x] = s * sor[PS + x];
+				}
+			}
+			__syncthreads();
+		}
+	}
+	for (int idx = tid; idx < (II - 2) * (JJ - 2); idx += NT) {
+		const int x = 1 + idx % (II - 2) + II * (1 + idx / (II - 2));
+		q[x] = qs[x];
+	}
+}
+} // namespace
+
+void relax_points_small(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int nstncl,
+                        int updown, int nsweeps, hipStream_t st, Batch bt)
+{
+	if (nsweeps <= 0) return;
+	const size_t shm = (size_t)II * JJ * sizeof(real_t); // 35 KB for a 66 x 66 level
+	const int work = ((II - 2 + 1) / 2) * ((JJ - 2 + 1) / 2);
+	const int nthr = work > 512 ? 1024 : work > 256 ? 512 : 256;
+	if (nstncl == 5)
+		hipLaunchKernelGGL(points_small_kernel<true>, dim3(bt.n), dim3(nthr), shm, st, so, qf, q, sor, II, JJ, updown, nsweeps, bt.stride);
+	else
+		hipLaunchKernelGGL(points_small_kernel<false>, dim3(bt.n), dim3(nthr), shm, st, so, qf, q, sor, II, JJ, updown, nsweeps, bt.stride);
+}
 
 // Dirichlet levels of at most 64 x 64 unknowns (CEDAR_AMD_LINES_SMALL=0: the per-colour kernels everywhere)
 bool lines_small_ok(int II, int JJ)

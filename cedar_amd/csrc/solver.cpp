@@ -326,6 +326,10 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 		relax_lines_small(L.A, b, x, L.SOR0, kind == 2 ? L.SOR0 : L.SOR1, L.II, L.JJ, L.nst, kind, updown, n, st, Batch{s->nb, L.npts});
 		return;
 	}
+	if (s->nd == 2 && s->st.ibc == 0 && s->st.relaxation == CEDAR_AMD_RELAX_POINT && lines_small_ok(L.II, L.JJ)) {
+		relax_points_small(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, n, st, Batch{s->nb, L.npts});
+		return;
+	}
 	for (int it = 0; it < n; it++) {
 		if (s->nd == 3 && s->st.relaxation >= CEDAR_AMD_RELAX_PLANE_XY) { // multilevel.h:179-189, :208-218
 			static const int down[3] = {0, 2, 1}, up[3] = {1, 2, 0}; // xy, yz, xz on the way down; xz, yz, xy on the way up

@@ -186,3 +186,25 @@ def test_small_level_line_sweeps_match_the_per_colour_kernels(capi, oracle, monk
         np.testing.assert_allclose(out[flag][0], ho, rtol=1e-10, atol=1e-12)
         assert np.max(np.abs(out[flag][1] - xo)) <= 1e-10 * np.max(np.abs(xo))
     assert np.max(np.abs(out["0"][1] - out["1"][1])) <= 1e-11 * np.max(np.abs(xo))
+
+
+@pytest.mark.parametrize("shape,op,cycle", [((64, 64), "aniso9", "v"), ((40, 33), "stretch5", "v"), ((130, 77), "aniso9", "v"),
+                                            ((96, 130), "stretch5", "f"), ((3, 5), "aniso9", "v"), ((512, 512), "stretch5", "v")], ids=str)
+def test_small_level_point_sweeps_are_bit_identical_to_the_per_colour_kernels(capi, monkeypatch, shape, op, cycle):
+    """levels of at most 64 x 64 unknowns run the colours of every point sweep of a visit in one launch
+    (lines_small.hip points_small_kernel): same expression per point, so the iterates equal those of the per-colour
+    launches (CEDAR_AMD_LINES_SMALL=0) bit for bit"""
+    nx, ny = shape
+    so = pb.aniso9(nx, ny) if op == "aniso9" else pb.diag_diffusion2(nx, ny, 1e-2, 1.0)
+    b = pb.rhs2(nx, ny)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CEDAR_AMD_LINES_SMALL", flag)
+        s = capi.Solver(so, relax="point", nrelax_pre=2, nrelax_post=1, cycle=cycle, max_iter=4)
+        x = np.zeros_like(b)
+        h = s.solve(b, x)
+        s.close()
+        out[flag] = (np.array(h), x)
+    assert np.array_equal(out["0"][1].view(np.int64), out["1"][1].view(np.int64))
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert len(out["1"][0]) >= 2 and np.all(np.isfinite(out["1"][0]))  # (point relaxation does not converge on aniso9: not the point)
