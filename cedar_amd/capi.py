@@ -75,6 +75,11 @@ def set_device(dev):
         raise RuntimeError(f"hipSetDevice({dev}) failed")
 
 
+def release_scratch():
+    """frees the device scratch the library keeps between calls (cedar_amd_release_scratch)"""
+    lib.cedar_amd_release_scratch()
+
+
 def sync():
     lib.cedar_amd_sync()
 

@@ -207,6 +207,11 @@ void cedar_amd_stream_wait(void *waiter, void *waited)
 }
 
 void cedar_amd_device_sync(void) { CEDAR_HIP_CHECK(hipDeviceSynchronize()); }
+void cedar_amd_release_scratch(void)
+{
+	CEDAR_HIP_CHECK(hipDeviceSynchronize());
+	cedar_amd::galerkin3_rows_release();
+}
 
 // ---- HIP events on the library's current stream (benchmarks time kernels with these, not with the host clock)
 void *cedar_amd_event_record(void)

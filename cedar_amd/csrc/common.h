@@ -194,6 +194,7 @@ bool galerkin3_tiled(const real_t *so, real_t *soc, const real_t *ci, int IIF, i
                      int IIC, int JJC, int KKC, int ifd, hipStream_t st);
 bool galerkin3_rows(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                     int IIC, int JJC, int KKC, int ifd, hipStream_t st);
+void galerkin3_rows_release(); // frees the kept ring of row sums
 bool galerkin3_rows_pairs(const real_t *so, int IIF); // the row sums can read the operator as aligned pairs
 void galerkin3(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                int IIC, int JJC, int KKC, int ifd, hipStream_t st);

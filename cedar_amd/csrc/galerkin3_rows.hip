@@ -307,6 +307,13 @@ bool galerkin3_rows_pairs(const real_t *so, int IIF)
 	return (!ep || atoi(ep) != 0) && IIF % 2 == 0 && ((uintptr_t)so & 15) == 0;
 }
 
+// cedar_amd_release_scratch: the caller has drained the device
+void galerkin3_rows_release()
+{
+	if (g_rows) (void)hipFree(g_rows);
+	g_rows = nullptr, g_rows_bytes = 0;
+}
+
 // returns false when the ring cannot be had (the caller then runs the one-stage kernels)
 bool galerkin3_rows(const real_t *so, real_t *soc, const real_t *ci, int IIF, int JJF, int KKF,
                     int IIC, int JJC, int KKC, int ifd, hipStream_t st)

@@ -305,6 +305,9 @@ void *cedar_amd_stream_create(void);
 void cedar_amd_stream_destroy(void *stream);
 void cedar_amd_stream_wait(void *waiter, void *waited);
 void cedar_amd_device_sync(void);
+/* Releases the device scratch the library keeps between calls (the ring of row sums of the 3D Galerkin product: 4.4 GB
+ * after a 512^3 set-up; it is re-allocated by the next product that needs it).  Waits for the device first. */
+void cedar_amd_release_scratch(void);
 /* HIP events on the library's current stream: record returns a new event; elapsed waits for e1 */
 void *cedar_amd_event_record(void);
 float cedar_amd_event_elapsed_ms(void *e0, void *e1);

@@ -348,3 +348,19 @@ def test_registered_solve_copy_gives_the_same_bits(K, monkeypatch):
         outs.append((x.numpy(), r.numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     so.free()  # cedar_amd_free releases the registration with the operator
+
+
+def test_release_scratch_between_galerkin_products(K):
+    """cedar_amd_release_scratch frees the kept ring of row sums; the next product allocates it again"""
+    import problems as pb
+    from cedar_amd import capi
+    g = (12, 14, 18)
+    gc = pb.coarse_shape(g)
+    so = pb.random_op(g, 14, 3, zero_ghost=False)
+    ci = pb.uniform((26,) + gc, 4, -1, 1)
+    a, b = np.zeros((14,) + gc), np.zeros((14,) + gc)
+    K.galerkin3(so, a, ci)
+    capi.release_scratch()
+    capi.release_scratch()  # nothing kept: no-op
+    K.galerkin3(so, b, ci)
+    assert np.any(a != 0) and np.array_equal(a, b)
