@@ -142,3 +142,33 @@ def test_plane_relaxation_refusals(capfd):
     del s
     s = capi.Solver(pb.poisson3(8, 8, 8), relax="plane-xy", plane=dict(relax="plane-xz"))
     assert "relaxation must be" in capfd.readouterr().err
+
+
+def _random_plane_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        nx, ny, nz = (int(v) for v in rng.integers(5, 24, size=3))
+        out.append((nx, ny, nz, int(rng.choice([4, 14])), str(rng.choice(["plane-xy", "plane-xz", "plane-yz", "plane-xyz"])),
+                    str(rng.choice(["v", "f"]))))
+    return out
+
+
+@pytest.mark.parametrize("nx,ny,nz,nst,relax,cycle", _random_plane_cases(10, 4102026), ids=str)
+def test_random_small_grids_with_plane_relaxation_follow_the_oracle(oracle, nx, ny, nz, nst, relax, cycle):
+    """seeded random extents: plane counts of either parity, planes whose 2D hierarchy has one to three levels"""
+    from cedar_amd import capi
+    so = varying_op(nx, ny, nz, nst, 17)
+    b = pb.uniform(so.shape[1:], 18, -1, 1) * pb.interior_mask(so.shape[1:])
+    s = capi.Solver(so, relax=relax, cycle=cycle, max_iter=3)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    ml = oracle.ml_create(so, relax=relax, cycle=cycle)
+    assert s.nlevels() == ml.nlevels()
+    s.close()
+    xo = np.zeros_like(b)
+    ho = ml.solve(b, xo, maxiter=3, tol=1e-8)
+    ml.close()
+    assert len(h) == len(ho)
+    np.testing.assert_allclose(h, ho, rtol=1e-8, atol=1e-13)
+    assert np.max(np.abs(x - xo)) <= 1e-9 * max(np.max(np.abs(xo)), 1e-300)

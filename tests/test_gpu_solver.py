@@ -208,3 +208,36 @@ def test_small_level_point_sweeps_are_bit_identical_to_the_per_colour_kernels(ca
     assert np.array_equal(out["0"][1].view(np.int64), out["1"][1].view(np.int64))
     assert np.array_equal(out["0"][0], out["1"][0])
     assert len(out["1"][0]) >= 2 and np.all(np.isfinite(out["1"][0]))  # (point relaxation does not converge on aniso9: not the point)
+
+
+def _random_2d_solver_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        nx, ny = (int(v) for v in rng.integers(3, 75, size=2))
+        relax = str(rng.choice(["point", "line-x", "line-y", "line-xy"]))
+        op = str(rng.choice(["aniso9", "stretch5", "fe2"]))
+        cycle = str(rng.choice(["v", "v", "f"]))
+        out.append((nx, ny, relax, op, cycle))
+    return out
+
+
+@pytest.mark.parametrize("nx,ny,relax,op,cycle", _random_2d_solver_cases(24, 20261004), ids=str)
+def test_random_small_2d_solvers_follow_the_oracle(capi, oracle, nx, ny, relax, op, cycle):
+    """seeded random extents around the 64 x 64 limit of the one-launch-per-visit kernels (levels on both sides of it in
+    one hierarchy, odd and even extents, lines of one to 74 unknowns): same level count and residual history as the oracle"""
+    so = pb.aniso9(nx, ny) if op == "aniso9" else pb.fe2(nx, ny) if op == "fe2" else pb.diag_diffusion2(nx, ny, 1e-2, 1.0)
+    b = pb.rhs2(nx, ny)
+    s = capi.Solver(so, relax=relax, cycle=cycle, max_iter=5)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    nl = s.nlevels()
+    s.close()
+    ml = oracle.ml_create(so, relax=relax, cycle=cycle)
+    assert nl == ml.nlevels()
+    xo = np.zeros_like(b)
+    ho = ml.solve(b, xo, maxiter=5)
+    ml.close()
+    assert len(h) == len(ho)
+    np.testing.assert_allclose(h, ho, rtol=1e-9, atol=1e-12)
+    assert np.max(np.abs(x - xo)) <= 1e-9 * max(np.max(np.abs(xo)), 1e-300)
