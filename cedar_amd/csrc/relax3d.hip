@@ -678,7 +678,10 @@ static int plane_frun(int JJ)
 		const int frun = atoi(e);
 		return (frun <= 0 || ny < 4 * frun) ? 0 : frun;
 	}
-	return ny >= 320 ? 8 : 0; // runs of 8 rows: within 1 % of the best run length at 320, 384, 448 and 512
+	// runs of 8 rows are within 1 % of the best run length from 320 to 512; with the row-interleaved solve copy runs of 16
+	// are another 1 % shorter at 384 and 512 (half as many rows between runs; interleaved A/B on two boxes,
+	// profiles/r02_experiment_run_length.log)
+	return ny >= 384 ? 16 : ny >= 320 ? 8 : 0;
 }
 
 // one row class (jb,kb) of the 27-point sweep, both i-colours (distributed runs exchange halos
