@@ -219,6 +219,11 @@ void relax_lines_y(const real_t *so, const real_t *qf, real_t *q, const real_t *
 void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st, Batch bt = Batch());
 // lines_small.hip: all line sweeps of one visit of a level of at most 64 x 64 unknowns in one launch
 bool lines_small_ok(int II, int JJ);
+// one half of a V-cycle visit of such a level in one launch: pre != 0: pre-smoothing, residual, restriction, coarse x := 0;
+// else interpolation-and-add, post-smoothing.  kind: 0 point relaxation (sorx = reciprocals), 1 / 2 / 3 = x / y / xy lines
+void visit_small(int pre, const real_t *so, const real_t *qf, real_t *q, real_t *res, const real_t *sorx, const real_t *sory,
+                 int II, int JJ, int nstncl, int kind, int nsweeps, const real_t *ci, real_t *cb, real_t *cx, int IIC, int JJC,
+                 hipStream_t st, Batch bf = Batch(), Batch bc = Batch());
 void relax_points_small(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int nstncl,
                         int updown, int nsweeps, hipStream_t st, Batch bt = Batch());
 void relax_lines_small(const real_t *so, const real_t *qf, real_t *q, const real_t *sorx, const real_t *sory,

@@ -386,6 +386,15 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 {
 	Level &L = s->lv[lvl], &K = s->lv[lvl + 1];
 	L.bt_fresh = false; // b of this visit has not been transposed yet
+	// a small 2D level: each half of the visit is one launch with the level resident in LDS (lines_small.hip)
+	const bool small = s->nd == 2 && s->st.ibc == 0 && s->st.relaxation <= CEDAR_AMD_RELAX_LINE_XY && lines_small_ok(L.II, L.JJ);
+	const int kind = s->st.relaxation == CEDAR_AMD_RELAX_POINT ? 0 : s->st.relaxation == CEDAR_AMD_RELAX_LINE_X ? 1
+	               : s->st.relaxation == CEDAR_AMD_RELAX_LINE_Y ? 2 : 3;
+	const real_t *sory = kind == 2 ? L.SOR0 : L.SOR1;
+	if (small) {
+		visit_small(1, L.A, b, x, L.res, L.SOR0, sory, L.II, L.JJ, L.nst, kind, s->st.nrelax_pre, K.P, K.b, K.x, K.II, K.JJ, st,
+		            Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
+	} else {
 	smooth(s, L, x, b, BMG_DOWN, s->st.nrelax_pre, st);
 	residual(s, L, x, b, L.res, st);
 	if (s->nd == 2 && s->st.ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, s->st.ibc, st);
@@ -393,8 +402,14 @@ void ncycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStream_
 	else if (s->st.ibc) restrict3_per(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, s->st.ibc, st);
 	else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
 	clear(K.x, K.npts * (size_t)s->nb, st); // coarse_x.set(0.0)
+	}
 	if (lvl + 1 == (int)s->lv.size() - 1) coarse_solve(s, K.x, K.b, st);
 	else ncycle(s, lvl + 1, K.x, K.b, st);
+	if (small) {
+		visit_small(0, L.A, b, x, L.res, L.SOR0, sory, L.II, L.JJ, L.nst, kind, s->st.nrelax_post, K.P, nullptr, K.x, K.II, K.JJ, st,
+		            Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
+		return;
+	}
 	if (s->nd == 2 && s->st.ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, s->st.ibc, st);
 	else if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st, Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
 	else if (s->st.ibc) interp_add3_per(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, s->st.ibc, st);
