@@ -1,16 +1,20 @@
-// Relaxation on a small 2D level, all sweeps of one visit in ONE launch: zebra lines, and point Gauss-Seidel below
-// (BMG2_SymStd_relax_lines_x.f90:75-176, relax_lines_y.f90:77-176; multilevel.h:179-218 for the order of the two
-// directions).
+// Small 2D levels (at most 64 x 64 unknowns, Dirichlet): each half of a V-cycle visit in ONE launch
+// (multilevel.h:170-218; BMG2_SymStd_relax_lines_x.f90:75-176, relax_lines_y.f90:77-176, relax_GS.f90:80-135,
+// residual.f90:90-98, restrict.f90, interp_add.f90).
 //
-// On a level of at most 64 x 64 unknowns a sweep of relax_lines_x / relax_lines_yt is latency: two colour launches per
-// direction plus the two transposes of a y sweep (and one of the right-hand side per visit), ~7 us each with a few
-// hundred points of work -- a line-xy V(2,1) visit is some twenty launches.  Plane relaxation runs one such 2D cycle
-// per plane colour and 3D level, so its V-cycle was bound by these launches (profiles/r02_plane_relaxation_vcycle.log:
-// 1900 kernels of ~7 us per cycle at 256^3).
-// Here one workgroup owns the level (one per batch item): the unknowns sit in LDS for the whole visit; per colour the
-// right-hand sides of its lines are formed by all lanes (reference term order), the factors of those lines are staged
-// beside them, and each line is solved by ONE lane sequentially -- DPTTRS's own order, so a line solve is the
-// reference's to the bit where the scan of the big-level kernels re-associates.
+// On such a level every kernel of the cycle is latency: two colour launches per line direction plus the two transposes of
+// a y sweep (and one of the right-hand side per visit), residual, restriction, a fill, interpolation -- ~7 us each with a
+// few hundred points of work; a line-xy V(2,1) visit was some twenty launches.  Plane relaxation runs one such 2D cycle per
+// plane colour and 3D level, so its V-cycle was bound by these launches (profiles/r02_plane_relaxation_vcycle.log: 1900
+// kernels of ~7 us per cycle at 256^3).
+// Here one workgroup owns the level (one per batch item) and the unknowns sit in LDS for the whole launch:
+//   visit_pre_small_kernel    pre-smoothing sweeps, residual, its restriction to the coarse right-hand side, coarse x := 0
+//   visit_post_small_kernel   interpolation-and-add of the coarse correction, post-smoothing sweeps
+//   lines_small_kernel / points_small_kernel   the sweeps alone (smooth() outside a V-cycle visit)
+// Line sweeps: per colour the right-hand sides of its lines are formed by all lanes (reference term order), the factors of
+// those lines are staged beside them, and each line is solved by ONE lane sequentially -- DPTTRS's own order, so a line solve
+// is the reference's to the bit where the scan of the big-level kernels re-associates.  Point sweeps, residual, restriction
+// and interpolation use the expressions of the per-launch kernels: bit-identical to them.
 #include "common.h"
 
 namespace cedar_amd {
