@@ -33,7 +33,7 @@ static TileShape env_tile(const char *name, unsigned tjl, unsigned tkl)
 	return ts;
 }
 TileShape tile_shape_relax() { static TileShape ts = env_tile("CEDAR_AMD_TILE_RELAX", 4, 4); return ts; }
-TileShape tile_shape_resid() { static TileShape ts = env_tile("CEDAR_AMD_TILE_RESID", 4, 4); return ts; }
+TileShape tile_shape_resid() { return env_tile("CEDAR_AMD_TILE_RESID", 4, 4); } // read per call (interleaved A/B runs)
 
 // ------------------------------------------------------------------ recip
 __global__ void recip_kernel(const real_t *__restrict__ d, real_t *__restrict__ r,
