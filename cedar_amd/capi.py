@@ -228,6 +228,12 @@ class Kernels:
         nst, KK, JJ, II = so.shape
         lib.BMG3_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), u(KK), int(nst == 4), nst, 2, 1, updown, ibc)
 
+    def relax3_psum(self, so, qf, q, sor, updown):
+        """27-point sweep with inter-plane partial sums (cedar_amd_relax3_gs_psum); returns 1 if that path ran"""
+        nst, KK, JJ, II = so.shape
+        assert nst == 14
+        return lib.cedar_amd_relax3_gs_psum(_p(so), _p(qf), _p(q), _p(sor), None, u(II), u(JJ), u(KK), updown)
+
     def residual3(self, so, qf, q, res):
         nst, KK, JJ, II = so.shape
         lib.BMG3_SymStd_residual(1, 1, int(nst == 4), _p(q), _p(qf), _p(so), _p(res), u(II), u(JJ), u(KK), nst)

@@ -502,6 +502,26 @@ int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_
 
 void cedar_amd_relax3_release(const real_t *so) { relax3_release(so); }
 
+int cedar_amd_relax3_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, real_t *scratch, len_t ii, len_t jj, len_t kk,
+                             int updown)
+{
+	const size_t P = (size_t)ii * jj * kk;
+	const int frun = relax3_plane_frun((int)jj);
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	if (!relax3_psum_ok((int)ii, (int)jj, (int)kk, frun)) {
+		relax3_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, 14, updown, current_stream());
+		return 0;
+	}
+	real_t *T = scratch && is_device_ptr(scratch) ? scratch : static_cast<real_t *>(pool_get(P * sizeof(real_t)));
+	relax3_gs27_psum(op3_cedar(sso.get(), ssor.get(), (int)ii, (int)jj, (int)kk), sqf.get(), sq.get(), T, (int)ii, (int)jj,
+	                 (int)kk, updown, frun, current_stream());
+	if (T != scratch) {
+		CEDAR_HIP_CHECK(hipStreamSynchronize(current_stream()));
+		pool_put(T, P * sizeof(real_t));
+	}
+	return 1;
+}
+
 void cedar_amd_relax3_colour7(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int pts)
 {
 	size_t P = (size_t)ii * jj * kk;

@@ -42,6 +42,8 @@ struct Level {
 	real_t *PFx = nullptr, *PFy = nullptr;
 	// 3D 27-point: row-interleaved solve copy of A and 1/diag (common.h Op3) read by relax and residual
 	real_t *Ailv = nullptr;
+	// 3D 27-point: partial-sum scratch of the relax sweep (relax3d_psum.hip), one vector
+	real_t *T = nullptr;
 	// the set-up products (A, P, SOR, At, PF*) belong to another solver of the same operator (plane relaxation:
 	// every plane solver of a direction is built from the same 2D operator); this level owns only its vectors
 	bool shared = false;
@@ -347,7 +349,8 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 			continue;
 		}
 		if (s->nd == 3) {
-			if (L.Ailv) relax3_gs27_op(op3_ilv(L.Ailv, L.II, L.JJ, L.KK), b, x, L.II, L.JJ, L.KK, updown, st);
+			if (L.Ailv) relax3_gs27_op(op3_ilv(L.Ailv, L.II, L.JJ, L.KK), b, x, L.II, L.JJ, L.KK, updown, st, L.T);
+			else if (L.T) relax3_gs27_op(op3_cedar(L.A, L.SOR0, L.II, L.JJ, L.KK), b, x, L.II, L.JJ, L.KK, updown, st, L.T);
 			else relax3_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.KK, L.nst, updown, st);
 			continue;
 		}
@@ -695,6 +698,8 @@ static cedar_amd_solver *solver_create(int nd, len_t nx, len_t ny, len_t nz, int
 				F.Ailv = dalloc_raw(ilv_doubles(F.II, F.JJ, F.KK));
 				ilv_build(F.A, F.SOR0 + F.npts, F.Ailv, F.II, F.JJ, F.KK, st);
 			}
+			// partial-sum scratch of the relax sweep: T is read only where the sweep wrote it, not cleared
+			if (F.nst == 14 && !s->st.ibc && relax3_psum_wanted(F.II, F.JJ, F.KK)) F.T = dalloc_raw(F.npts);
 		}
 	}
 	if (nd == 2 && s->st.ibc) setup_cg2_per(C.A, C.II, C.JJ, C.nst, s->ABD, s->nabd1, s->st.ibc, s->dinfo, st);
@@ -728,7 +733,7 @@ void cedar_amd_solver_destroy(cedar_amd_solver *s)
 			(void)hipFree(L.P); (void)hipFree(L.SOR0); (void)hipFree(L.SOR1); (void)hipFree(L.At); (void)hipFree(L.Ailv);
 			(void)hipFree(L.PFx); (void)hipFree(L.PFy);
 		}
-		(void)hipFree(L.res); (void)hipFree(L.yscr); (void)hipFree(L.bt); (void)hipFree(L.xt);
+		(void)hipFree(L.res); (void)hipFree(L.yscr); (void)hipFree(L.bt); (void)hipFree(L.xt); (void)hipFree(L.T);
 		if (l > 0) { (void)hipFree(L.x); (void)hipFree(L.b); }
 	}
 	if (!s->shared_abd) (void)hipFree(s->ABD);

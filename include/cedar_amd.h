@@ -169,6 +169,17 @@ void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len
  * the operator changed; release before freeing it.  The resident solver (section 2) does this by itself. */
 int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk);
 void cedar_amd_relax3_release(const real_t *so);
+/* One 27-point sweep (BMG3_SymStd_relax_GS.f90:80-138, Dirichlet) with INTER-PLANE PARTIAL SUMS: the planes of the
+ * first k-parity are relaxed in the reference's order and leave, per point of the planes between them, the sums of the
+ * nine products towards the plane below and above; the second k-parity adds those two sums to its eight in-plane terms
+ * instead of re-reading eighteen operator slot-rows.  Same products as the reference, the 26-term sum of :104-131
+ * re-associated for the second k-parity: results agree with BMG3_SymStd_relax_GS to rounding (not bit for bit); this is
+ * the sweep the resident solver runs on levels with at least 320 rows (CEDAR_AMD_PSUM=0: reference order).  scratch: a
+ * device array of the vector's size, or NULL (the library takes one from its pool).  Run length: CEDAR_AMD_FRUN.
+ * Returns 1, or 0 when the level cannot take it (rows longer than 512 points, fewer than four runs per plane) and the
+ * reference-order sweep was run instead. */
+int cedar_amd_relax3_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, real_t *scratch, len_t ii, len_t jj, len_t kk,
+                             int updown);
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb);

@@ -106,6 +106,39 @@ def test_plane_fused_relax_matches_four_pass_order(K, oracle, monkeypatch, shape
         assert np.array_equal(got, want), (shape, frun, ud, np.max(np.abs(got - want)))
 
 
+@pytest.mark.parametrize("frun", [2, 3, 4, 8])
+@pytest.mark.parametrize("shape", [(20, 16, 5), (9, 17, 4), (70, 18, 6), (130, 19, 3), (11, 33, 7), (257, 34, 8), (512, 20, 9),
+                                   (3, 16, 16), (4, 9, 3)], ids=str)
+def test_partial_sum_relax_matches_reference_order_to_rounding(K, oracle, monkeypatch, shape, frun):
+    """cedar_amd_relax3_gs_psum (relax3d_psum.hip): the 27-point sweep whose second k-parity takes its inter-plane
+    terms as two partial sums left by the first -- same products as BMG3_SymStd_relax_GS.f90:104-131, re-associated.
+    Every run length, odd and even nx / ny / nz (ghost columns as sources, rows at run ends, planes next to a ghost
+    plane), non-zero ghost cells and ghost operator entries, both directions, three sweeps in a row.
+    Tolerance: 2e-14 of max|q| per sweep (a few roundings of a 27-term sum; the reference order is kept bit for bit
+    by BMG3_SymStd_relax_GS, tested above)."""
+    import problems as pb
+    monkeypatch.setenv("CEDAR_AMD_FRUN", str(frun))
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    so = pb.random_op(g, 14, 71, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 72, -1, 1), pb.uniform(g, 73, -1, 1)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip3(so, sor)
+    took = 0
+    for ud in (0, 1):
+        want, got = q0.copy(), q0.copy()
+        for sweep in range(3):
+            oracle.relax3(so, qf, want, sor, ud)
+            took += K.relax3_psum(so, qf, got, sor, ud)
+            scale = np.max(np.abs(want))
+            assert np.max(np.abs(got - want)) <= 2e-14 * (sweep + 1) * scale, (shape, frun, ud, sweep, np.max(np.abs(got - want)) / scale)
+        # ghost cells are never written
+        m = np.ones(g, bool)
+        m[1:-1, 1:-1, 1:-1] = False
+        assert np.array_equal(got[m], q0[m])
+    assert took == (6 if ny >= 4 * frun else 0)
+
+
 @pytest.mark.parametrize("frun", [1, 2, 3, 0])
 @pytest.mark.parametrize("shape", [(300, 48), (131, 33), (1100, 25), (260, 24)], ids=str)
 def test_band_fused_relax9_matches_two_pass_order(K, oracle, monkeypatch, shape, frun):

@@ -40,6 +40,34 @@ def test_solve_history_vs_reference_golden(capi, golden, name):
     np.testing.assert_allclose(h, want, rtol=1e-10, atol=cases.HIST_ATOL.get(name, 1e-14))
 
 
+@pytest.mark.parametrize("frun", [2, 4])
+@pytest.mark.parametrize("name", ["fe27_40x33x50_v21", "fe27_65_v21", "fe27_129_v21", "fe27_40x33x50_f21"], ids=str)
+def test_solve_history_with_partial_sum_relax_vs_reference_golden(capi, golden, monkeypatch, name, frun):
+    """the resident solver with the partial-sum relax sweep (relax3d_psum.hip; by default on levels with >= 320 rows,
+    here forced onto every level with at least 4 runs of `frun` rows): the reference's residual histories with the
+    SAME tolerances as the reference-order solver above"""
+    monkeypatch.setenv("CEDAR_AMD_FRUN", str(frun))
+    monkeypatch.setenv("CEDAR_AMD_PSUM", "1")
+    mk_op, mk_rhs, st = cases.SOLVES[name]
+    gold = golden["solves"][name]
+    so, b = mk_op(), mk_rhs()
+    s = capi.Solver(so, **st)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    s.close()
+    want = [float(gold["res0_l2"])] + [float(v) for v in gold["rel_l2"]]
+    np.testing.assert_allclose(h, want, rtol=1e-10, atol=cases.HIST_ATOL.get(name, 1e-14))
+    # and it is not the reference-order sweep in disguise: some iterate differs in the last bits
+    monkeypatch.setenv("CEDAR_AMD_PSUM", "0")
+    s = capi.Solver(so, **st)
+    x2 = np.zeros_like(b)
+    h2 = s.solve(b, x2)
+    s.close()
+    np.testing.assert_allclose(h2, want, rtol=1e-10, atol=cases.HIST_ATOL.get(name, 1e-14))
+    assert not np.array_equal(x, x2)
+    assert np.max(np.abs(x - x2)) <= 1e-12 * np.max(np.abs(x2))
+
+
 @pytest.mark.parametrize("name", ["varcoef9_200x120_v21", "fe27_40x33x50_v21", "poisson7_64_v21",
                                   "stretch5_800x200_linex", "poisson5_400_v11"], ids=str)
 def test_hierarchy_vs_oracle(capi, oracle, name):
