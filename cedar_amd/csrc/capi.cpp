@@ -4,6 +4,7 @@
 #include "../../include/cedar_amd.h"
 #include "common.h"
 #include "stage.h"
+#include "relax3_psum.h"
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -506,7 +507,7 @@ int cedar_amd_relax3_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, rea
                              int updown)
 {
 	const size_t P = (size_t)ii * jj * kk;
-	const int frun = relax3_plane_frun((int)jj);
+	const int frun = relax3_psum_frun((int)jj);
 	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
 	if (!relax3_psum_ok((int)ii, (int)jj, (int)kk, frun)) {
 		relax3_gs(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, 14, updown, current_stream());

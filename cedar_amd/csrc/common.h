@@ -97,13 +97,6 @@ void relax3_gs(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
 // T: scratch of the vector's size for the partial-sum sweep (relax3d_psum.hip), nullptr = reference order always
 void relax3_gs27_op(const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, int KK, int updown, hipStream_t st,
                     real_t *T = nullptr);
-// F rows per workgroup of the plane-fused walk on a level with JJ-2 rows (0 = row-class launches), relax3d.hip
-int relax3_plane_frun(int JJ);
-// relax3d_psum.hip: 27-point sweep with inter-plane partial sums (north_star's 1e-10 contract, not bit for bit)
-bool relax3_psum_ok(int II, int JJ, int KK, int frun);
-bool relax3_psum_wanted(int II, int JJ, int KK); // the level takes it by default (CEDAR_AMD_PSUM, run length, row length)
-void relax3_gs27_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int updown, int frun,
-                      hipStream_t st);
 void residual27_op(const Op3 &A, const real_t *qf, const real_t *q, real_t *res, int II, int JJ, int KK, hipStream_t st);
 void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                      int II, int JJ, int KK, int kb, int up, int part, hipStream_t st);

@@ -1,0 +1,17 @@
+// Host-side entry points of the 27-point sweep variants (relax3d.hip, relax3d_psum.hip).
+#pragma once
+#include "common.h"
+
+namespace cedar_amd {
+
+// F rows per workgroup of the plane-fused walk on a level with JJ-2 rows (0 = row-class launches), relax3d.hip
+int relax3_plane_frun(int JJ);
+// relax3d_psum.hip: 27-point sweep with inter-plane partial sums (north_star's 1e-10 contract, not bit for bit)
+bool relax3_psum_ok(int II, int JJ, int KK, int frun);
+bool relax3_psum_wanted(int II, int JJ, int KK); // the level takes it by default (CEDAR_AMD_PSUM, run length, row length)
+void relax3_gs27_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int updown, int frun,
+                      hipStream_t st);
+// run length of the partial-sum sweep on a level with JJ-2 rows (0 = the level keeps the reference order), relax3d.hip
+int relax3_psum_frun(int JJ);
+
+} // namespace cedar_amd

@@ -20,6 +20,7 @@
 // reference's CPU build.
 #include "common.h"
 #include "relax27_dev.h"
+#include "relax3_psum.h"
 #include <map>
 
 namespace cedar_amd {
@@ -626,19 +627,39 @@ void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t
 	}
 }
 
-// CEDAR_AMD_PSUM: 0 = reference order everywhere; unset / 1 = partial sums where the plane-fused walk runs
+// Run length of the partial-sum sweep (relax3d_psum.hip).  A longer run leaves fewer rows in the reference order (3 in
+// 2*frun) but fewer workgroups per launch.  Measured, ms per sweep for runs of 8 / 16 / 32 rows against the reference-order
+// sweep of that level (profiles/r03_psum_run_length.log; single runs scatter by +-5 % with the placement of the level):
+//   512^3 4.70 / 4.23 / 4.47 (and 4.75 / 4.53 / 4.40 / 4.37 for 8 / 16 / 32 / 64 on another box) against 6.17;
+//   448^3 3.19 / 3.21 / 3.45 against 4.20;  384^3 2.04 / 1.96 / 2.08;  320^3 1.27 / 1.28 / 1.32 against 1.58;
+//   256^3 0.71 / 0.65 / 0.66 against 0.79 (0.69 for the four row-class launches);  224^3 0.47 / 0.47 / 0.52 against 0.53;
+//   192^3 0.30 / 0.31 / 0.45 against 0.34;  128^3 slower than the row-class launches for every length.
+// CEDAR_AMD_FRUN overrides as for the plane-fused walk (n = runs of n rows wherever a plane has at least 4 of them).
+int relax3_psum_frun(int JJ)
+{
+	const char *e = getenv("CEDAR_AMD_FRUN"); // read per call: the tests switch it between cases
+	const int ny = JJ - 2;
+	if (e) {
+		const int frun = atoi(e);
+		return (frun <= 0 || ny < 4 * frun) ? 0 : frun;
+	}
+	return ny >= 480 ? 32 : ny >= 224 ? 16 : ny >= 160 ? 8 : 0;
+}
+
+// CEDAR_AMD_PSUM: 0 = reference order everywhere; unset / 1 = partial sums on the levels relax3_psum_frun names
 bool relax3_psum_wanted(int II, int JJ, int KK)
 {
 	const char *e = getenv("CEDAR_AMD_PSUM"); // read per call: the tests switch it between cases
 	if (e && atoi(e) == 0) return false;
-	return relax3_psum_ok(II, JJ, KK, relax3_plane_frun(JJ));
+	return relax3_psum_ok(II, JJ, KK, relax3_psum_frun(JJ));
 }
 
 void relax3_gs27_op(const Op3 &A, const real_t *qf, real_t *q, int II, int JJ, int KK, int updown, hipStream_t st, real_t *T)
 {
 	if (II < 3 || JJ < 3 || KK < 3) return;
-	if (T && relax3_psum_wanted(II, JJ, KK) && !getenv("CEDAR_AMD_WHATIF") && !getenv("CEDAR_AMD_KCHUNK")) {
-		relax3_gs27_psum(A, qf, q, T, II, JJ, KK, updown, relax3_plane_frun(JJ), st);
+	const char *ew0 = getenv("CEDAR_AMD_WHATIF"), *ec0 = getenv("CEDAR_AMD_KCHUNK");
+	if (T && relax3_psum_wanted(II, JJ, KK) && !(ew0 && atoi(ew0)) && !(ec0 && atoi(ec0))) {
+		relax3_gs27_psum(A, qf, q, T, II, JJ, KK, updown, relax3_psum_frun(JJ), st);
 		return;
 	}
 	{

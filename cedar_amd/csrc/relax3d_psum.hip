@@ -29,6 +29,7 @@
 // the A plane above, which needs none).
 #include "common.h"
 #include "relax27_dev.h"
+#include "relax3_psum.h"
 
 namespace cedar_amd {
 

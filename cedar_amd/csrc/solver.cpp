@@ -13,6 +13,7 @@
 #include "../../include/cedar_amd.h"
 #include "common.h"
 #include "stage.h"
+#include "relax3_psum.h"
 #include <cmath>
 #include <cstring>
 #include <utility>
