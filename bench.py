@@ -18,6 +18,10 @@ Extra keys in the JSON line:
                / average launch duration measured live with HIP events on the library's stream
   cpu_baseline the oracle (C restatement of the reference, kind "port") timed on one host
                core on a bounded sample of the same workload
+  level0_kernels   N = 1, 3d27: the other level-0 kernels of the cycle (residual27_rows, restrict3, interp_add3) against the
+               HBM roofline: algorithmic bytes / launch time from HIP events (cedar_amd_solver_time_op)
+  other_workloads  N = 1, default run only: BASELINE configs 2 and 3 (2d9 4096^2 point, 2d9l 8192^2 line-xy) timed the same
+               way in this process after the 3D solver has been released: ms_per_step, DOF/s, relax launch time and frac
   ms_per_step_per_allocation  N = 1: the W warm-up + K timed steps are run on every one of the fresh allocations the
                roofline launch time is taken over (default 3), and `value` / `ms_per_step` are the MEDIAN: where the
                operator lands in device memory moves a sweep by +-6 %, and the headline should
@@ -149,6 +153,37 @@ def cpu_baseline(wl, relax):
                       f"(one per host core of {cpu_model}, no halo cost charged); single rank alone: {one['dof_per_s']:.3e} DOF/s; {one['what']}"}
 
 
+def other_workload(capi, wl, steps=10, warmup=3):
+    """one of the 2D BASELINE configs on the resident single-GPU solver: V-cycle time and the level-0 relax launch"""
+    nd, n, relax, bytes_per_dof, launches, label = WORKLOADS[wl]
+    so, b = build_problem(capi, wl, n)
+    capi.sync()
+    t0 = time.perf_counter()
+    s = capi.Solver(so, relax=relax, share_operator=True)
+    capi.sync()
+    setup = time.perf_counter() - t0
+    x = capi.DeviceArray(b.shape)
+    for _ in range(warmup):
+        s.vcycle(x, b)
+    capi.lib.cedar_amd_device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.vcycle(x, b)
+    capi.lib.cedar_amd_device_sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    s.time_relax(x, b, 4)
+    lm = s.time_relax(x, b, 40) / (40 * launches)
+    dof = float(n) ** nd
+    alg = bytes_per_dof * dof / launches
+    out = {"workload": label.format(n=n), "ms_per_step": ms, "value": dof / (ms * 1e-3), "unit": "DOF/s", "steps": steps,
+           "warmup": warmup, "levels": s.nlevels(), "setup_ms": setup * 1e3,
+           "relax_launch_ms": lm, "relax_algorithmic_bytes_per_launch": alg, "relax_launches_per_sweep": launches,
+           "relax_achieved_GBps": alg / (lm * 1e-3) / 1e9, "relax_frac": alg / (lm * 1e-3) / 8e12}
+    s.close()
+    so.free(); b.free(); x.free()
+    return out
+
+
 def visible_gpus():
     """number of GPUs this box shows, counted in a child process so that the caller stays free of any HIP state"""
     import subprocess
@@ -173,13 +208,32 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll all ranks: the first one that fails takes the others down (they would otherwise block forever inside RCCL
+    # or the bootstrap waiting for it); an overall deadline bounds a hang of all of them
+    deadline = time.time() + float(os.environ.get("CEDAR_AMD_BENCH_DEADLINE", "3000"))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            sys.stderr.write("bench.py: ranks still running at the deadline, stopping them\n")
+            rc = 124
+            break
+        time.sleep(0.2)
     if rc:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
                 p.kill()
     sys.exit(rc)
 
@@ -195,6 +249,8 @@ def main():
     ap.add_argument("--workload", default="3d27", choices=list(WORKLOADS))
     ap.add_argument("--size", type=int, default=0, help="override the per-GPU grid extent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default 3d27 run: skip the 2d9 / 2d9l timings appended as other_workloads")
     ap.add_argument("--allocations", type=int, default=3,
                     help="N=1: fresh operator allocations the roofline launch time is the median of")
     ap.add_argument("--strong", action="store_true",
@@ -216,6 +272,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     nd, n_default, relax, bytes_per_dof, launches, label = WORKLOADS[args.workload]
     relax_kernel = "relax27_plane" if nd == 3 else relax
+    psum = nd == 3 and world == 1 and os.environ.get("CEDAR_AMD_PSUM", "1") != "0"
+    if psum:
+        # the resident solver's sweep with inter-plane partial sums (relax3d_psum.hip): its two halves differ (the first
+        # k-parity also forms the partial sums, the second reads two partial-sum rows instead of 18 slot-rows), so the
+        # roofline unit is the WHOLE sweep: relax27_planeA + relax27_rows_between + relax27_rows_sel + relax27_planeB +
+        # relax27_rows_sel, 136 B x n^3 algorithmic bytes
+        launches, relax_kernel = 1, "one sweep = relax27_planeA + relax27_planeB + 3 row launches (relax27_rows_between, relax27_rows_sel x2)"
     if world > 4 and nd == 3:  # rank grids with a y split exchange halos after every row class: four launches per sweep
         launches, relax_kernel = 4, "relax27_rows"
     # (2 and 4 GPUs run z slabs: a whole k-parity -- the plane-fused kernel -- between two exchanges)
@@ -381,18 +444,27 @@ def main():
             per_alloc.append(s2.time_relax(x2, b2, nsw) / (nsw * launches))
             s2.close()
             so2.free(); b2.free(); x2.free()
-    if world == 1 and setups and args.allocations > 1 and (min(setups) > 4 * 0.05 * (dof / 512.0 ** 3 if nd == 3 else 1.0)
-                                                           or os.environ.get("CEDAR_AMD_BENCH_SETUP_RETRY") == "1"):
-        # every creation so far mapped device memory other processes had used and paid the driver's clearing of it
-        # (hundreds of ms, profiles/r02_setup_time_allocations.log): create / release on the resident operator a few more
-        # times -- a creation that gets released blocks back shows the set-up itself
-        for _ in range(3):
+    if world == 1 and setups and args.allocations > 1:
+        # a creation that maps device memory the process has not held before also pays the driver's clearing of it (hundreds
+        # of ms on a box other processes have used, profiles/r02_setup_time_allocations.log): ALWAYS two more create / release
+        # rounds on the resident operator, which reuse released blocks and show the set-up itself
+        for _ in range(2):
             capi.sync()
             ts = time.perf_counter()
             s3 = capi.Solver(so, relax=relax, share_operator=True)
             capi.sync()
             setups.append(time.perf_counter() - ts)
             s3.close()
+    level0 = None
+    if world == 1 and nd == 3 and hasattr(solver, "time_op"):
+        # the other level-0 kernels of the cycle against the same roofline (algorithmic bytes: SURVEY 8d / DESIGN section 5)
+        level0 = {}
+        for op, kname, bpd in (("residual", "residual27_rows", 136.0), ("restrict", "restrict3_kernel", 35.0),
+                               ("interp_add", "interp_add3_kernel", 67.0)):
+            solver.time_op(x, b, op, 2)
+            t = solver.time_op(x, b, op, 10) / 10
+            level0[kname] = {"launch_ms": t, "algorithmic_bytes_per_launch": bpd * dof,
+                             "achieved": bpd * dof / (t * 1e-3) / 1e9, "unit": "GB/s", "frac": bpd * dof / (t * 1e-3) / 8e12}
     launch_ms = sorted(per_alloc)[len(per_alloc) // 2]
     ms_per_step = sorted(step_ms)[len(step_ms) // 2]
     alg_bytes_launch = bytes_per_dof * dof / launches
@@ -401,7 +473,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if n == n_default:  # the PMC passes were taken at the benchmark size
-            traffic = pmc.get(args.workload + ("_rows" if world > 4 else ""), {}).get("hbm_bytes_per_launch")
+            traffic = pmc.get(args.workload + ("_psum_sweep" if psum else "_rows" if world > 4 else ""), {}).get("hbm_bytes_per_launch")
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "relax sweep level 0 (%s)" % relax_kernel,
@@ -443,13 +515,26 @@ def main():
             # box other processes have used: profiles/r02_setup_time_allocations.log) and, for the very first one,
             # code-object loading; a creation that reuses released blocks shows the set-up itself.  All values are listed.
             "setup_ms": None if not setups else min(setups) * 1e3,
-            "setup_ms_is": "minimum over %d solver creations in this process (see setup_ms_per_allocation)" % len(setups),
+            "setup_ms_is": "minimum over %d solver creations in this process (setup_ms_first = the first creation, what a "
+                           "one-shot user pays incl. code-object loading and the driver's clearing of fresh device memory; "
+                           "setup_ms_median; all in setup_ms_per_allocation)" % len(setups),
+            "setup_ms_first": None if not setups else setups[0] * 1e3,
+            "setup_ms_median": None if not setups else sorted(setups)[len(setups) // 2] * 1e3,
             "setup_ms_per_allocation": [v * 1e3 for v in setups],
         }
+        if level0:
+            out["level0_kernels"] = level0
+        if world == 1 and args.workload == "3d27" and not args.size and not args.no_other_workloads:
+            # BASELINE configs 2 and 3 in the same line (the driver runs the default command only)
+            solver.close()
+            solver = None
+            so.free(); b.free(); x.free()
+            out["other_workloads"] = {wl: other_workload(capi, wl) for wl in ("2d9", "2d9l")}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, relax)
         print(json.dumps(out), flush=True)
-    solver.close()
+    if solver is not None:
+        solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

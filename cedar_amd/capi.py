@@ -307,6 +307,8 @@ lib.cedar_amd_solver_time_vcycles.restype = C.c_float
 lib.cedar_amd_solver_time_vcycles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 lib.cedar_amd_solver_time_relax.restype = C.c_float
 lib.cedar_amd_solver_time_relax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.cedar_amd_solver_time_op.restype = C.c_float
+lib.cedar_amd_solver_time_op.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
 lib.cedar_amd_gallery.argtypes = [C.c_int, C.c_void_p, C.c_void_p, u, u, u, C.c_void_p]
 
 
@@ -394,6 +396,10 @@ class Solver:
 
     def time_relax(self, x, b, n):
         return lib.cedar_amd_solver_time_relax(self.h, x.ptr, b.ptr, n)
+
+    def time_op(self, x, b, op, n):
+        """n launches of a level-0 kernel: op 'residual' | 'restrict' | 'interp_add' (overwrites x); elapsed ms"""
+        return lib.cedar_amd_solver_time_op(self.h, x.ptr, b.ptr, {"residual": 1, "restrict": 2, "interp_add": 3}[op], n)
 
     def close(self):
         if self.h:

@@ -926,4 +926,40 @@ float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real
 	return ms;
 }
 
+// n launches of one level-0 transfer / residual kernel: op 1 = residual (res := b - A x), 2 = restriction of res to level 1,
+// 3 = interpolation-and-add from level 1 (overwrites x and res: timing only)
+float cedar_amd_solver_time_op(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int op, int n)
+{
+	if (null_handle(s, "cedar_amd_solver_time_op")) return 0.f;
+	if (s->lv.size() < 2 || op < 1 || op > 3) return 0.f;
+	hipStream_t st = current_stream();
+	Level &L = s->lv[0], &K = s->lv[1];
+	const int ibc = s->st.ibc;
+	hipEvent_t e0, e1;
+	CEDAR_HIP_CHECK(hipEventCreate(&e0));
+	CEDAR_HIP_CHECK(hipEventCreate(&e1));
+	CEDAR_HIP_CHECK(hipEventRecord(e0, st));
+	for (int i = 0; i < n; i++) {
+		if (op == 1) residual(s, L, x_dev, b_dev, L.res, st);
+		else if (op == 2) {
+			if (s->nd == 2 && ibc) restrict2_per(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, ibc, st);
+			else if (s->nd == 2) restrict2(L.res, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st, Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
+			else if (ibc) restrict3_per(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, ibc, st);
+			else restrict3(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
+		} else {
+			if (s->nd == 2 && ibc) interp_add2_per(x_dev, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, ibc, st);
+			else if (s->nd == 2) interp_add2(x_dev, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st, Batch{s->nb, L.npts}, Batch{s->nb, K.npts});
+			else if (ibc) interp_add3_per(x_dev, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, ibc, st);
+			else interp_add3(x_dev, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
+		}
+	}
+	CEDAR_HIP_CHECK(hipEventRecord(e1, st));
+	CEDAR_HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	CEDAR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	launch_check("cedar_amd_solver_time_op");
+	return ms;
+}
+
 } // extern "C"

@@ -274,6 +274,10 @@ float cedar_amd_solver_time_vcycles(cedar_amd_solver *s, real_t *x_dev, const re
 /* n relax sweeps on level 0 alternating DOWN/UP (the roofline microbenchmark);
  * returns elapsed milliseconds (HIP events on the library's stream) */
 float cedar_amd_solver_time_relax(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int n);
+/* n launches of one level-0 kernel of the cycle besides the sweep: op 1 = residual, 2 = restriction of the residual to
+ * level 1, 3 = interpolation-and-add from level 1 (overwrites x and the residual: a timing aid, not a solver step);
+ * returns elapsed milliseconds (HIP events on the library's stream) */
+float cedar_amd_solver_time_op(cedar_amd_solver *s, real_t *x_dev, const real_t *b_dev, int op, int n);
 
 /* plane relaxation as a kernel of its own -- kernels::plane_relax<stypes, rdir>::setup(so) / run(so, x, b, dir)
  * (include/cedar/kernels/plane_relax.h:10-33; include/cedar/3d/relax_planes.h:164-246, src/3d/relax_planes.cc).
