@@ -383,6 +383,13 @@ class Solver:
         shp = (ny + 2, nx + 2) if self.nd == 2 else (nz + 2, ny + 2, nx + 2)
         return out.reshape((-1,) + shp)
 
+    def set_array(self, lvl, what, a):
+        """replace a set-up product of a level (cedar_amd_solver_set); a: numpy array of the product's full size"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        n = lib.cedar_amd_solver_get(self.h, lvl, what.encode(), None)
+        assert n == a.size, (what, lvl, n, a.size)
+        assert lib.cedar_amd_solver_set(self.h, lvl, what.encode(), a.ctypes.data) == n
+
     def vcycle(self, x, b):
         lib.cedar_amd_solver_vcycle(self.h, _vp(x), _vp(b))
 

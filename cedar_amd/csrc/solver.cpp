@@ -207,6 +207,8 @@ void lines_y(const Level &L, real_t *x, const real_t *b, const real_t *sor, int 
 
 // ------------------------------------------------------------------ plane relaxation
 void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st);
+bool graph_prepare(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st);
+bool graph_ready(const cedar_amd_solver *s, const real_t *x, const real_t *b);
 double l2_dev(cedar_amd_solver *s, const Level &L, const real_t *v);
 void residual(const cedar_amd_solver *s, const Level &L, const real_t *x, const real_t *b, real_t *r, hipStream_t st);
 
@@ -293,6 +295,17 @@ void planes_relax(cedar_amd_solver *s3, PlaneSet &ps, const Level &L, real_t *x,
 			if (S <= 1) {
 				for (int q = 0; q < n; q++) cycle_on(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q, st);
 			} else {
+				// Every instance's graph is recorded and instantiated BEFORE the first replay of this colour is launched,
+				// with the device idle: capture / hipGraphInstantiate never run beside replays in flight on the side streams
+				// (the first visit used to interleave them; DESIGN.md section 6, the rocprofv3 abort of round 2).
+				bool missing = false;
+				for (int q = 0; q < n; q++)
+					missing = missing || !graph_ready(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q);
+				if (missing) {
+					CEDAR_HIP_CHECK(hipDeviceSynchronize());
+					for (int q = 0; q < n; q++)
+						if (ps.inst[q]->use_graph) graph_prepare(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q, s3->pstreams[q % S]);
+				}
 				CEDAR_HIP_CHECK(hipEventRecord(s3->pfork, st));
 				for (int t = 0; t < S; t++) CEDAR_HIP_CHECK(hipStreamWaitEvent(s3->pstreams[t], s3->pfork, 0));
 				for (int q = 0; q < n; q++) cycle_on(ps.inst[q], ps.x2s + ps.P2 * q, ps.b2s + ps.P2 * q, s3->pstreams[q % S]);
@@ -452,12 +465,10 @@ void cycle_launch(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t s
 void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st);
 void cycle_dev(cedar_amd_solver *s, real_t *x, const real_t *b) { cycle_on(s, x, b, current_stream()); }
 
-void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
+// make s->gexec the instantiated graph of one cycle on (x, b) with the current batch count; returns true if it had to be
+// recorded.  `st`: the stream earlier replays of this solver's graph were launched on (drained before a stale graph goes).
+bool graph_prepare(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 {
-	if (!s->use_graph) {
-		cycle_launch(s, x, b, st);
-		return;
-	}
 	if (s->gexec && (s->gx != x || s->gb != b)) {
 		CEDAR_HIP_CHECK(hipStreamSynchronize(st)); // a replay of the old graph may still be running
 		CEDAR_HIP_CHECK(hipGraphExecDestroy(s->gexec));
@@ -475,7 +486,8 @@ void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 			s->gexec = nullptr;
 		}
 	}
-	if (!s->gexec) {
+	if (s->gexec) return false;
+	{
 		// one capture stream for the process: captures are recorded synchronously (thread-local mode), and plane
 		// relaxation keeps hundreds of small solvers whose graphs are all recorded through here
 		static hipStream_t capture_stream = nullptr;
@@ -491,6 +503,21 @@ void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
 		CEDAR_HIP_CHECK(hipGraphDestroy(g));
 		s->gx = x; s->gb = b; s->gnb = s->nb;
 	}
+	return true;
+}
+
+bool graph_ready(const cedar_amd_solver *s, const real_t *x, const real_t *b)
+{
+	return !s->use_graph || (s->gexec && s->gx == x && s->gb == b && s->gnb == s->nb);
+}
+
+void cycle_on(cedar_amd_solver *s, real_t *x, const real_t *b, hipStream_t st)
+{
+	if (!s->use_graph) {
+		cycle_launch(s, x, b, st);
+		return;
+	}
+	graph_prepare(s, x, b, st);
 	CEDAR_HIP_CHECK(hipGraphLaunch(s->gexec, st));
 }
 
@@ -780,6 +807,36 @@ size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what
 	else if (!strcmp(what, "x")) { src = L.x; n = L.x ? L.npts : 0; } // coarse levels only: level 0 uses the caller's
 	else if (!strcmp(what, "b")) { src = L.b; n = L.b ? L.npts : 0; }
 	if (out && n) cedar_amd_memcpy_d2h(out, src, n * sizeof(real_t));
+	return n;
+}
+
+// levels[lvl].A / .P / .SOR / ABD are public members of the reference's solver (include/cedar/level.h:14-41,
+// include/cedar/2d/solver.h:56): a caller may replace a set-up product.  Solver-internal copies that derive from the
+// array (row-interleaved solve copy, transposed y-line planes, scan-ordered line factors) are rebuilt.
+size_t cedar_amd_solver_set(cedar_amd_solver *s, int lvl, const char *what, const real_t *in)
+{
+	if (null_handle(s, "cedar_amd_solver_set") || lvl < 0 || lvl >= (int)s->lv.size() || !in) return 0;
+	Level &L = s->lv[lvl];
+	hipStream_t st = current_stream();
+	real_t *dst = nullptr;
+	size_t n = 0;
+	if (!strcmp(what, "A")) { dst = L.A; n = L.npts * L.nst; }
+	else if (!strcmp(what, "P")) { dst = L.P; n = L.P ? L.npts * (s->nd == 3 ? 26 : 8) : 0; }
+	else if (!strcmp(what, "SOR0")) { dst = L.SOR0; n = L.npts * 2; }
+	else if (!strcmp(what, "SOR1")) { dst = L.SOR1; n = L.SOR1 ? L.npts * 2 : 0; }
+	else if (!strcmp(what, "ABD")) { dst = s->ABD; n = (size_t)s->nabd1 * s->nabd2; }
+	if (!dst || !n) return 0;
+	CEDAR_HIP_CHECK(hipDeviceSynchronize()); // no cycle in flight while a product changes
+	if (is_device_ptr(in)) cedar_amd_memcpy_d2d(dst, in, n * sizeof(real_t));
+	else cedar_amd_memcpy_h2d(dst, in, n * sizeof(real_t));
+	if (L.Ailv && (!strcmp(what, "A") || !strcmp(what, "SOR0")))
+		ilv_build(L.A, L.SOR0 + L.npts, L.Ailv, L.II, L.JJ, L.KK, st);
+	if (L.At && !strcmp(what, "A")) setup_lines_yt(L.A, L.At, L.II, L.JJ, L.nst, st);
+	if (L.PFx && !strcmp(what, "SOR0")) lines_permute(L.SOR0, L.PFx, L.nx, L.II, L.ny, L.npts, st);
+	if (L.PFy && !strcmp(what, s->st.relaxation == CEDAR_AMD_RELAX_LINE_Y ? "SOR0" : "SOR1"))
+		lines_permute(s->st.relaxation == CEDAR_AMD_RELAX_LINE_Y ? L.SOR0 : L.SOR1, L.PFy, L.ny, L.JJ, L.nx, L.npts, st);
+	CEDAR_HIP_CHECK(hipStreamSynchronize(st));
+	launch_check("cedar_amd_solver_set");
 	return n;
 }
 

@@ -264,6 +264,10 @@ void cedar_amd_solver_level_dims(const cedar_amd_solver *s, int lvl, len_t *nx, 
  * levels "x","b" (level 0 works on the caller's x and b);
  * returns the number of doubles written (0 if absent); out may be NULL to query. */
 size_t cedar_amd_solver_get(const cedar_amd_solver *s, int lvl, const char *what, real_t *out);
+/* replace a set-up product of a level (what = "A","P","SOR0","SOR1","ABD"; `in` host or device, the array's full size):
+ * the reference's `levels` container exposes these as public members (include/cedar/level.h:14-41).  Copies the solver
+ * derives from the array are rebuilt.  Returns the number of doubles taken (0: no such array). */
+size_t cedar_amd_solver_set(cedar_amd_solver *s, int lvl, const char *what, const real_t *in);
 /* one V-cycle, cycle->run(x,b): x,b host or device */
 void cedar_amd_solver_vcycle(cedar_amd_solver *s, real_t *x, const real_t *b);
 /* multilevel::solve(b,x): rel[0] = ||r0||_2, rel[i] = ||r_i||_2/||r0||_2; returns cycles run */

@@ -25,6 +25,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import cases  # noqa: E402
+import problems as pb  # noqa: E402
 from pyoracle import Ref, DOWN, UP  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -302,8 +303,38 @@ def main_periodic(R):
         json.dump(hist, f, indent=1)
 
 
+# cases whose reference-built hierarchy is committed (small ones): tests upload it into the device-resident solver and run
+# the SOLVE PHASE alone -- what is left of the late-cycle history deviation then belongs to the solve kernels
+HIERARCHIES = {
+    "fe27_24x20x17_v21": (lambda: pb.fe3(24, 20, 17), lambda: pb.rhs3(24, 20, 17), dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "fe27_40x33x50_v21": (lambda: pb.fe3(40, 33, 50), lambda: pb.rhs3(40, 33, 50), dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+    "varcoef9_72x50_v21": (lambda: pb.varcoef9(72, 50), lambda: pb.rhs2(72, 50), dict(relax="point", nrelax_pre=2, nrelax_post=1)),
+}
+
+
+def hierarchies(R):
+    """the reference's set-up products of a few small cases (A and P of the coarse levels, relaxation data, the factored
+    coarsest operator) and the residual history of 10 cycles on them"""
+    for name, (mk_op, mk_rhs, st) in HIERARCHIES.items():
+        so, b = mk_op(), mk_rhs()
+        ml = RefML(R, so, **st)
+        x = np.zeros_like(b)
+        h = ml.solve(b, x, maxiter=10, tol=1e-8)
+        out = {"hist": np.array(h), "abd": ml.abd, "nlev": np.array(ml.nlev)}
+        for l in range(ml.nlev):
+            if l > 0:
+                out["A%d" % l] = ml.A[l]
+                out["P%d" % l] = ml.P[l]
+            if l < ml.nlev - 1:
+                out["SOR0_%d" % l] = ml.SOR[l][0]
+        np.savez_compressed(os.path.join(GOLD, "hier_%s.npz" % name), **out)
+        print(name, ml.nlev, h[0], h[-1], flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "periodic":  # regenerate only the periodic fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == "hierarchy":
+        hierarchies(Ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "periodic":  # regenerate only the periodic fixtures
         os.makedirs(GOLD, exist_ok=True)
         main_periodic(Ref())
     elif len(sys.argv) > 1 and sys.argv[1] == "periodic3":

@@ -40,6 +40,59 @@ def test_solve_history_vs_reference_golden(capi, golden, name):
     np.testing.assert_allclose(h, want, rtol=1e-10, atol=cases.HIST_ATOL.get(name, 1e-14))
 
 
+HIER = {
+    "fe27_24x20x17_v21": (lambda: pb.fe3(24, 20, 17), lambda: pb.rhs3(24, 20, 17), dict(relax="point")),
+    "fe27_40x33x50_v21": (lambda: pb.fe3(40, 33, 50), lambda: pb.rhs3(40, 33, 50), dict(relax="point")),
+    "varcoef9_72x50_v21": (lambda: pb.varcoef9(72, 50), lambda: pb.rhs2(72, 50), dict(relax="point")),
+}
+
+
+@pytest.mark.parametrize("name", list(HIER), ids=str)
+def test_solve_phase_on_the_reference_hierarchy(capi, name):
+    """Where the late-cycle deviation of the histories comes from.  The reference's OWN set-up
+    products (coarse operators, interpolation, relaxation data, factored coarsest operator: tests/golden/hier_*.npz,
+    oracle/gen_golden.py hierarchy) are uploaded into the resident solver (cedar_amd_solver_set) and the SOLVE PHASE runs
+    on the device.  No absolute floor here:
+      * 3D 27-point: every cycle of the reference history to 1e-12 relative (measured: bit for bit) -- relax, residual,
+        restriction and interpolation-and-add reproduce the reference's arithmetic exactly at every level; what the
+        histories of test_solve_history_vs_reference_golden show beyond cycle 5 is the set-up (Galerkin association);
+      * 2D: the same up to the coarsest-grid triangular solve, where the reference's LAPACK (MKL DPBTRS in this image;
+        the reference pins none, CMakeLists.txt:49-50) and the netlib operation order the library restates differ by
+        3e-16 of the coarse solution (oracle/gen_golden.py pins this: the only solve-phase kernel whose output differs
+        on identical inputs) -- enough for 1e-10 relative once the residual has fallen seven decades, so the last
+        cycles are held to the floor of the other history tests and the first four to 1e-12."""
+    import os
+    mk_op, mk_rhs, st = HIER[name]
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "hier_%s.npz" % name))
+    so, b = mk_op(), mk_rhs()
+    s = capi.Solver(so, **st)
+    nlev = int(fx["nlev"])
+    assert s.nlevels() == nlev
+    x = np.zeros_like(b)
+    h_own = s.solve(b, x)
+    for l in range(nlev):
+        if l > 0:
+            s.set_array(l, "A", fx["A%d" % l])
+            s.set_array(l, "P", fx["P%d" % l])
+        if l < nlev - 1:
+            s.set_array(l, "SOR0", fx["SOR0_%d" % l])
+    s.set_array(0, "ABD", fx["abd"])
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    s.close()
+    want = fx["hist"]
+    assert len(h) == len(want)
+    dev = np.abs(np.array(h) - want) / want
+    dev_own = np.abs(np.array(h_own) - want) / want
+    if so.ndim == 4:
+        assert np.all(dev <= 1e-12), dev
+        # the library's own set-up is what moves the late cycles (same solve kernels, same right-hand side)
+        assert dev_own[-1] > 10 * max(dev[-1], 1e-16) or dev_own[-1] <= 1e-12, (dev_own, dev)
+    else:
+        assert np.all(dev[:5] <= 1e-12), dev
+        np.testing.assert_allclose(h, want, rtol=1e-10, atol=1e-14)
+
+
 @pytest.mark.parametrize("frun", [2, 4])
 @pytest.mark.parametrize("name", ["fe27_40x33x50_v21", "fe27_65_v21", "fe27_129_v21", "fe27_40x33x50_f21"], ids=str)
 def test_solve_history_with_partial_sum_relax_vs_reference_golden(capi, golden, monkeypatch, name, frun):

@@ -90,3 +90,41 @@ def test_solver_meets_reference_acceptance(oracle):
     assert h[-1] * h[0] < 1e-8
     err = np.max(np.abs((pb.exact2(200, 200) - x)[1:-1, 1:-1]))
     assert err < 1e-4
+
+
+@pytest.mark.parametrize("name", ["fe27_24x20x17_v21", "fe27_40x33x50_v21", "varcoef9_72x50_v21"], ids=str)
+def test_oracle_solve_phase_on_the_reference_hierarchy(name):
+    """the oracle's solve-phase kernels, chained by the reference's cycle (oracle/gen_golden.py RefML), on the reference's
+    own set-up products (tests/golden/hier_*.npz): the 3D history is reproduced to 1e-12 at every cycle (no floor), the
+    2D one through cycle 4 and then within the floor -- the coarsest-grid DPBTRS of the reference's LAPACK is the one
+    solve-phase kernel whose result differs (3e-16) from the netlib order the oracle and the library restate"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import problems as pb
+    from gen_golden import RefML
+    from pyoracle import Oracle
+    mk = {"fe27_24x20x17_v21": (lambda: pb.fe3(24, 20, 17), lambda: pb.rhs3(24, 20, 17)),
+          "fe27_40x33x50_v21": (lambda: pb.fe3(40, 33, 50), lambda: pb.rhs3(40, 33, 50)),
+          "varcoef9_72x50_v21": (lambda: pb.varcoef9(72, 50), lambda: pb.rhs2(72, 50))}[name]
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "hier_%s.npz" % name))
+    so, b = mk[0](), mk[1]()
+    ml = RefML(Oracle(), so, relax="point", nrelax_pre=2, nrelax_post=1)
+    assert ml.nlev == int(fx["nlev"])
+    for l in range(ml.nlev):
+        if l > 0:
+            ml.A[l][...] = fx["A%d" % l]
+            ml.P[l][...] = fx["P%d" % l]
+        if l < ml.nlev - 1:
+            ml.SOR[l][0][...] = fx["SOR0_%d" % l]
+    ml.abd[...] = fx["abd"]
+    x = np.zeros_like(b)
+    h = np.array(ml.solve(b, x, maxiter=10, tol=1e-8))
+    want = fx["hist"]
+    assert len(h) == len(want)
+    dev = np.abs(h - want) / want
+    if so.ndim == 4:
+        assert np.all(dev <= 1e-12), dev
+    else:
+        assert np.all(dev[:5] <= 1e-12), dev
+        np.testing.assert_allclose(h, want, rtol=1e-10, atol=1e-14)
