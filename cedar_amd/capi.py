@@ -232,7 +232,7 @@ class Kernels:
         """27-point sweep with inter-plane partial sums (cedar_amd_relax3_gs_psum); returns 1 if that path ran"""
         nst, KK, JJ, II = so.shape
         assert nst == 14
-        return lib.cedar_amd_relax3_gs_psum(_p(so), _p(qf), _p(q), _p(sor), None, u(II), u(JJ), u(KK), updown)
+        return lib.cedar_amd_relax3_gs_psum(_p(so), _p(qf), _p(q), _p(sor), C.cast(None, P), u(II), u(JJ), u(KK), updown)
 
     def residual3(self, so, qf, q, res):
         nst, KK, JJ, II = so.shape
@@ -301,6 +301,8 @@ lib.cedar_amd_solver_nlevels.argtypes = [C.c_void_p]
 lib.cedar_amd_solver_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(u), C.POINTER(u), C.POINTER(u)]
 lib.cedar_amd_solver_get.restype = C.c_size_t
 lib.cedar_amd_solver_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+lib.cedar_amd_solver_set.restype = C.c_size_t
+lib.cedar_amd_solver_set.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
 lib.cedar_amd_solver_vcycle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 lib.cedar_amd_solver_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.cedar_amd_solver_time_vcycles.restype = C.c_float
