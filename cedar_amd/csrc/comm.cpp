@@ -151,11 +151,18 @@ int cedar_amd_comm_exchange(cedar_amd_comm *c, int nsend, const int *speer, cons
 	hipStream_t st = current_stream();
 	NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
 	// receives first: the order inside a group does not matter to RCCL, but a self-message (rank talking to
-	// itself in the one-GPU rehearsal) needs both halves in the same group anyway
-	for (int i = 0; i < nrecv; i++)
-		if (rcount[i]) NCCL_TRY(rccl().Recv(rbuf[i], rcount[i], ncclDouble, rpeer[i], c->c, st), "ncclRecv");
-	for (int i = 0; i < nsend; i++)
-		if (scount[i]) NCCL_TRY(rccl().Send(sbuf[i], scount[i], ncclDouble, speer[i], c->c, st), "ncclSend");
+	// itself in the one-GPU rehearsal) needs both halves in the same group anyway.  A failure inside the bracket
+	// closes the group before returning: an open group would swallow every later RCCL call of the process.
+	ncclResult_t e = ncclSuccess;
+	const char *what = "";
+	for (int i = 0; i < nrecv && e == ncclSuccess; i++)
+		if (rcount[i]) { e = rccl().Recv(rbuf[i], rcount[i], ncclDouble, rpeer[i], c->c, st); what = "ncclRecv"; }
+	for (int i = 0; i < nsend && e == ncclSuccess; i++)
+		if (scount[i]) { e = rccl().Send(sbuf[i], scount[i], ncclDouble, speer[i], c->c, st); what = "ncclSend"; }
+	if (e != ncclSuccess) {
+		(void)rccl().GroupEnd();
+		return fail(what, e);
+	}
 	NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
 	return 0;
 }

@@ -334,6 +334,49 @@ void cedar_amd_event_destroy(void *event);
 
 const char *cedar_amd_version(void);
 
+/* ------------------------------------------------------------------ 4. the domain-decomposed 3D solver (one rank per GPU)
+ * cdr3::mpi::solver of the reference (include/cedar/3d/mpi/solver.h:76-89,232-233) for Dirichlet problems, point
+ * relaxation, V(pre,post): Cartesian block decomposition with one ghost layer, global-parity colouring, a ghost
+ * exchange after every row class of a sweep / residual / interp_add and between the phases of the set-up
+ * (src/3d/ftn/mpi/BMG3_SymStd_relax_GS.f90:102-147, ..._residual.f90:130, ..._interp_add.f90:308,
+ * ..._SETUP_interp_OI.f90:418-1074, ..._SETUP_ITLI27_ex.f90:1803), norm all-reduce (3d/mpi/grid_func.h:41), coarse levels
+ * gathered onto every rank (in place of 3d/mpi/redist_solver.h:221-224).  The whole cycle is orchestrated below this ABI
+ * (cedar_amd/csrc/dist3.cpp); a rank process only creates the handle and calls it.  rank = k*px*py + j*px + i
+ * (src/3d/util/topo.cc:82-84); every local extent must stay even on the distributed levels.
+ * Transport: `comm` (section 3, RCCL) -- or `transport`, a caller-supplied table, the counterpart of the reference's
+ * halo_exchanger plug-in (include/cedar/kernel.h:25-37, kernel_manager::add_halo): exchange has the contract of
+ * cedar_amd_comm_exchange (device buffers, ordered with the library's current stream), allgather that of
+ * cedar_amd_comm_allgather, allreduce_sum sums n HOST doubles in place over the ranks.  Each returns 0 on success. */
+typedef struct {
+	void *ctx;
+	int (*exchange)(void *ctx, int nsend, const int *speer, const real_t *const *sbuf, const size_t *scount,
+	                int nrecv, const int *rpeer, real_t *const *rbuf, const size_t *rcount);
+	int (*allgather)(void *ctx, const real_t *send, real_t *recv, size_t count);
+	int (*allreduce_sum)(void *ctx, double *host_values, int n);
+} cedar_amd_transport;
+typedef struct cedar_amd_dist3 cedar_amd_dist3;
+/* the rank grid used when pgrid is NULL: 1x1xN z slabs up to 4 ranks, 2x2x2 for 8 (BASELINE config 5), else the most
+ * cubic factorisation */
+void cedar_amd_dist3_rank_grid(int world, int pgrid[3]);
+/* A_local: DEVICE array (nstencil, nz+2, ny+2, nx+2) of this rank's part of the global operator (entries coupling to a
+ * neighbouring rank present; its ghost layers are filled here); it must outlive the handle.  settings: nrelax_pre /
+ * nrelax_post / max_iter / tol / min_coarse are used.  agglomerate_below (0 = 64): a level with at most that many
+ * points per direction and rank is gathered and continued on the single-domain solver.  overlap_min (0 = 96): levels
+ * with at least that many points per direction run the y/z halo of a row class on a side stream under the interior
+ * rows of the next.  Collective: every rank of the communicator calls it. */
+cedar_amd_dist3 *cedar_amd_dist3_create(cedar_amd_comm *comm, const cedar_amd_transport *transport, int rank, int world,
+                                        const int pgrid[3], real_t *A_local, len_t nx, len_t ny, len_t nz, int nstencil,
+                                        const cedar_amd_settings *settings, int agglomerate_below, int overlap_min);
+void cedar_amd_dist3_destroy(cedar_amd_dist3 *d);
+int cedar_amd_dist3_nlevels(const cedar_amd_dist3 *d);            /* levels of the global hierarchy */
+int cedar_amd_dist3_distributed_levels(const cedar_amd_dist3 *d); /* of which this many are distributed (the last one gathered) */
+/* one V-cycle on this rank's device-resident x, b (local boxes incl. ghost layer) */
+void cedar_amd_dist3_vcycle(cedar_amd_dist3 *d, real_t *x_dev, real_t *b_dev);
+/* mpi::solver::solve: rel[0] = ||r0||_2, rel[i] = ||r_i||_2 / ||r0||_2 (global norms); returns the cycles run */
+int cedar_amd_dist3_solve(cedar_amd_dist3 *d, real_t *b_dev, real_t *x_dev, real_t *rel);
+/* n level-0 sweeps (alternating DOWN / UP) with their halo exchanges; elapsed ms by HIP events */
+float cedar_amd_dist3_time_relax(cedar_amd_dist3 *d, real_t *x_dev, real_t *b_dev, int n);
+
 #ifdef __cplusplus
 }
 #endif

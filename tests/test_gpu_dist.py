@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
+def _worker(rank, world, port, n, pgrid, outdir, overlap_min, driver="python"):
     for p in (HERE, ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -53,7 +53,12 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min):
         A = be.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m)
         b = be.from_numpy(np.ascontiguousarray(gb[sl]) * m)
         x = be.zeros(b.shape)
-        s = DistSolver3(be, topo, A, max_iter=5, overlap_min=overlap_min)
+        if driver == "native":  # the orchestration below the C ABI (cedar_amd/csrc/dist3.cpp); Python hands over arrays + transport
+            from cedar_amd.dist3 import DistSolver3 as Native
+            s = Native(comm, rank, world, A, pgrid=pgrid, max_iter=5, overlap_min=overlap_min)
+            assert s.coord == topo.coord
+        else:
+            s = DistSolver3(be, topo, A, max_iter=5, overlap_min=overlap_min)
         h = s.solve(b, x)
         np.save(os.path.join(outdir, f"x{rank}.npy"), x.numpy())
         if rank == 0:
@@ -76,23 +81,21 @@ def _spawn(target, world, args):
     assert not bad, f"rank processes failed: exit codes {bad}"
 
 
-# overlap_min = 4: the y/z halo of a row pass travels on a side HIP stream under the interior rows of
-# the next pass wherever the level has an interior (the production default, 96, would leave these
-# small grids on the in-order path, which the first two cases keep covering)
-@pytest.mark.parametrize("n,pgrid,overlap_min", [((16, 12, 10), (2, 1, 1), 96), ((8, 8, 8), (2, 2, 1), 96),
-                                                 ((12, 10, 16), (1, 1, 2), 4), ((8, 8, 8), (1, 2, 2), 4),
-                                                 ((8, 8, 8), (2, 2, 1), 4), ((64, 64, 64), (1, 1, 2), 16), ((20, 16, 8), (1, 1, 4), 4),
-                                                 # 320 rows: the slab path runs the plane-fused kernel on level 0
-                                                 ((12, 320, 8), (1, 1, 2), 4),
-                                                 # 6.5e6 unknowns: plane-fused level 0 under a halo in flight, three
-                                                 # distributed levels, gathered 16x80x80 coarse problem
-                                                 ((64, 320, 160), (1, 1, 2), 32)],
-                         ids=["2ranks-x", "4ranks-xy", "2ranks-z-overlap", "4ranks-yz-overlap", "4ranks-xy-overlap",
-                              "2ranks-z-64cubed-overlap", "4ranks-z-slabs-overlap", "2ranks-z-plane-fused", "2ranks-z-6M-unknowns"])
-def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, oracle):
+CASES = [((16, 12, 10), (2, 1, 1), 96), ((8, 8, 8), (2, 2, 1), 96),
+         ((12, 10, 16), (1, 1, 2), 4), ((8, 8, 8), (1, 2, 2), 4),
+         ((8, 8, 8), (2, 2, 1), 4), ((64, 64, 64), (1, 1, 2), 16), ((20, 16, 8), (1, 1, 4), 4),
+         # 320 rows: the slab path runs the plane-fused kernel on level 0
+         ((12, 320, 8), (1, 1, 2), 4),
+         # 6.5e6 unknowns: plane-fused level 0 under a halo in flight, three
+         # distributed levels, gathered 16x80x80 coarse problem
+         ((64, 320, 160), (1, 1, 2), 32)]
+IDS = ["2ranks-x", "4ranks-xy", "2ranks-z-overlap", "4ranks-yz-overlap", "4ranks-xy-overlap",
+       "2ranks-z-64cubed-overlap", "4ranks-z-slabs-overlap", "2ranks-z-plane-fused", "2ranks-z-6M-unknowns"]
+
+
+def _check_against_single_domain(n, pgrid, tmp_path, oracle):
     import problems as pb
     world = pgrid[0] * pgrid[1] * pgrid[2]
-    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), overlap_min))
     gn = tuple(n[d] * pgrid[d] for d in range(3))
     g = (gn[2] + 2, gn[1] + 2, gn[0] + 2)
     gso = pb.random_op(g, 14, 77)
@@ -111,6 +114,28 @@ def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, 
         ref = x[ck * n[2]:ck * n[2] + n[2] + 2, cj * n[1]:cj * n[1] + n[1] + 2, ci * n[0]:ci * n[0] + n[0] + 2]
         own = (slice(1, -1),) * 3
         assert np.max(np.abs(xr[own] - ref[own])) <= 1e-12 * np.max(np.abs(x))
+
+
+@pytest.mark.parametrize("n,pgrid,overlap_min", CASES, ids=IDS)
+def test_native_driver_ranks_sharing_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, oracle):
+    """cedar_amd_dist3_* (the distributed V-cycle below the C ABI, cedar_amd/csrc/dist3.cpp) on 2 and 4 ranks sharing
+    the GPU over the host-staged transport handed in as the ABI's transport table: the single-domain history and
+    solution, on every rank grid shape, with and without the overlapped y/z halo, slab and row-class sweeps"""
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), overlap_min, "native"))
+    _check_against_single_domain(n, pgrid, tmp_path, oracle)
+
+
+# overlap_min = 4: the y/z halo of a row pass travels on a side HIP stream under the interior rows of
+# the next pass wherever the level has an interior (the production default, 96, would leave these
+# small grids on the in-order path, which the first two cases keep covering)
+@pytest.mark.parametrize("n,pgrid,overlap_min", [CASES[0], CASES[3], CASES[4], CASES[7]], ids=[IDS[0], IDS[3], IDS[4], IDS[7]])
+def test_two_ranks_one_gpu_equal_single_domain(n, pgrid, overlap_min, tmp_path, oracle):
+    """the same orchestration in Python on the GPU backend (cedar_amd/dist.py: the statement of the algorithm that also
+    runs on the CPU against the oracle, tests/test_dist_cpu.py)"""
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), overlap_min))
+    _check_against_single_domain(n, pgrid, tmp_path, oracle)
 
 
 def _rccl_worker(rank, world, port, outdir):
@@ -154,6 +179,13 @@ def _rccl_worker(rank, world, port, outdir):
     s = DistSolver3(be, Topology(0, 1), be.from_numpy(so), max_iter=4, agglomerate_below=8)
     x = be.zeros(b.shape)
     out["hist"] = [float(v) for v in s.solve(be.from_numpy(b), x)]
+    # and the native driver with the RCCL communicator handle (all-gather + all-reduce inside the library)
+    from cedar_amd.dist3 import DistSolver3 as Native
+    A2 = be.from_numpy(so)
+    s2 = Native(comm, 0, 1, A2, max_iter=4, agglomerate_below=8)
+    x2 = be.zeros(b.shape)
+    out["hist_native"] = s2.solve(be.from_numpy(b), x2)
+    s2.close()
     comm.close()
     import json
     json.dump(out, open(os.path.join(outdir, "rccl.json"), "w"))
@@ -175,3 +207,4 @@ def test_rccl_transport_one_rank(tmp_path, oracle):
     want = ml.solve(b, x, maxiter=4)
     ml.close()
     np.testing.assert_allclose(out["hist"], want, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(out["hist_native"], want, rtol=1e-10, atol=1e-14)
