@@ -335,7 +335,14 @@ def main():
             pp = (C.c_double * 6)(*place)
             capi.lib.cedar_amd_gallery(112, A.ptr, bt.ptr, ln[0], ln[1], ln[2], pp)  # fe3 placed in the global grid
             dof = float(ln[0]) * ln[1] * ln[2]
-            dsolver = DistSolver3(be, topo, A)
+            # the distributed cycle runs below the C ABI (cedar_amd_dist3_*, cedar_amd/csrc/dist3.cpp): one call per
+            # V-cycle from here, no per-kernel Python loop; CEDAR_AMD_DIST_DRIVER=python keeps the Python statement of
+            # the same orchestration (cedar_amd/dist.py) for A/B runs
+            if os.environ.get("CEDAR_AMD_DIST_DRIVER", "native") == "python":
+                dsolver = DistSolver3(be, topo, A)
+            else:
+                from cedar_amd.dist3 import DistSolver3 as NativeDist3
+                dsolver = NativeDist3(comm, rank, world, A, pgrid=topo.p)
             xt = be.zeros(g)
         else:
             # 2D workloads: n^2 per GPU of a (px n) x (py n) global grid, cedar_amd/dist2d.py.  The
@@ -370,6 +377,8 @@ def main():
                 return dsolver.nlev_global
 
             def time_relax(self, x_, b_, k):
+                if hasattr(dsolver, "time_relax"):
+                    return dsolver.time_relax(xt, bt, k)
                 from cedar_amd.comm import EventTimer
                 t = EventTimer()  # HIP events on the library's stream (the null stream torch shares in the 2D case)
                 for i in range(k):

@@ -85,12 +85,24 @@ def _recv_exact(s, n):
     return out
 
 
+def _job_tag(world):
+    """16 bytes that identify THIS job on a shared host: base MASTER_PORT, world size and a run id when the launcher
+    exports one (torch.distributed.run: TORCHELASTIC_RUN_ID; anything: CEDAR_AMD_RUN_ID).  Two jobs with neighbouring
+    MASTER_PORTs scan overlapping port ranges; the tag keeps their handshakes apart."""
+    import hashlib
+    rid = os.environ.get("CEDAR_AMD_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    key = "%s:%d:%s" % (os.environ.get("MASTER_PORT", "29500"), world, rid)
+    return hashlib.sha1(key.encode()).digest()[:16]
+
+
 def bootstrap_bytes(payload, rank, world, timeout=120.0, tag=b""):
-    """rank 0 hands `payload` (bytes) to every other rank over TCP on MASTER_ADDR; returns the payload everywhere"""
+    """rank 0 hands `payload` (bytes) to every other rank over TCP on MASTER_ADDR; returns the payload everywhere.
+    Handshake: client -> magic + job tag + its rank; rank 0 answers magic + job tag + payload only to ranks 1..world-1 of
+    the same job that it has not served yet, and the client checks the echoed tag before it accepts the payload."""
     if world == 1:
         return payload
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    magic = _MAGIC + tag
+    magic = _MAGIC + tag + _job_tag(world)
     if rank == 0:
         srv, err = None, None
         for port in _ports():
@@ -105,18 +117,21 @@ def bootstrap_bytes(payload, rank, world, timeout=120.0, tag=b""):
             raise RuntimeError(f"bootstrap: no free port next to MASTER_PORT: {err}")
         srv.listen(world)
         srv.settimeout(timeout)
-        served = 0
-        while served < world - 1:
+        served = set()
+        while len(served) < world - 1:
             conn, _ = srv.accept()
             with conn:
                 conn.settimeout(timeout)
                 try:
                     if _recv_exact(conn, len(magic)) != magic:
-                        continue
+                        continue  # another job (or a foreign client): not counted, not answered
+                    (r,) = struct.unpack("<I", _recv_exact(conn, 4))
                 except (ConnectionError, socket.timeout):
                     continue
+                if not 1 <= r < world or r in served:
+                    continue
                 conn.sendall(magic + struct.pack("<I", len(payload)) + payload)
-                served += 1
+                served.add(r)
         srv.close()
         return payload
     deadline = time.time() + timeout
@@ -125,9 +140,9 @@ def bootstrap_bytes(payload, rank, world, timeout=120.0, tag=b""):
             try:
                 with socket.create_connection((host, port), timeout=2.0) as s:
                     s.settimeout(3.0)  # a foreign service on a candidate port does not answer: move on
-                    s.sendall(magic)
+                    s.sendall(magic + struct.pack("<I", rank))
                     if _recv_exact(s, len(magic)) != magic:
-                        continue
+                        continue  # not this job's rank 0
                     (n,) = struct.unpack("<I", _recv_exact(s, 4))
                     return _recv_exact(s, n)
             except (OSError, ConnectionError):
@@ -263,20 +278,24 @@ class SocketComm:
             srv.listen(self.world)
             srv.settimeout(120.0)
             table, conns = {0: my_port}, []
+            magic = _MAGIC + _job_tag(self.world)
             while len(table) < self.world:
                 conn, _a = srv.accept()
                 conn.settimeout(60.0)
                 try:
-                    if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
+                    if _recv_exact(conn, len(magic)) != magic:
                         conn.close()
                         continue
                     r, p = struct.unpack("<II", _recv_exact(conn, 8))
                 except (ConnectionError, socket.timeout):
                     conn.close()
                     continue
+                if not 1 <= r < self.world or r in table:  # a rank of another job, or the same rank twice
+                    conn.close()
+                    continue
                 table[r] = p
                 conns.append(conn)
-            blob = struct.pack("<%dI" % self.world, *[table[r] for r in range(self.world)])
+            blob = magic + struct.pack("<%dI" % self.world, *[table[r] for r in range(self.world)])
             for conn in conns:
                 conn.sendall(blob)
                 conn.close()
@@ -288,7 +307,10 @@ class SocketComm:
                 try:
                     with socket.create_connection((host, port), timeout=2.0) as s:
                         s.settimeout(120.0)
-                        s.sendall(_MAGIC + struct.pack("<II", self.rank, my_port))
+                        magic = _MAGIC + _job_tag(self.world)
+                        s.sendall(magic + struct.pack("<II", self.rank, my_port))
+                        if _recv_exact(s, len(magic)) != magic:
+                            continue  # another job's rank 0
                         blob = _recv_exact(s, 4 * self.world)
                         return list(struct.unpack("<%dI" % self.world, blob))
                 except (OSError, ConnectionError):

@@ -425,7 +425,40 @@ void setup(cedar_amd_dist3 *d)
 
 } // namespace
 
+namespace {
+// loop-back transport: every message of the rank grid is packed, copied device to device in place of the send / receive,
+// and unpacked -- the ghost values are meaningless, the work per cycle is that of one rank of the grid.  A measuring aid
+// (tools/dist_overhead.py: what one rank costs beside its messages) for boxes with a single GPU.
+int loop_world = 1;
+int loop_exchange(void *, int ns, const int *, const real_t *const *sbuf, const size_t *scount, int nr, const int *,
+                  real_t *const *rbuf, const size_t *rcount)
+{
+	for (int i = 0; i < ns && i < nr; i++)
+		cedar_amd_memcpy_d2d(rbuf[i], sbuf[i], (scount[i] < rcount[i] ? scount[i] : rcount[i]) * sizeof(real_t));
+	return 0;
+}
+int loop_allgather(void *, const real_t *send, real_t *recv, size_t count)
+{
+	for (int r = 0; r < loop_world; r++) cedar_amd_memcpy_d2d(recv + (size_t)r * count, send, count * sizeof(real_t));
+	return 0;
+}
+int loop_allreduce(void *, double *v, int n)
+{
+	for (int i = 0; i < n; i++) v[i] *= loop_world;
+	return 0;
+}
+} // namespace
+
 extern "C" {
+
+void cedar_amd_transport_loopback(cedar_amd_transport *out, int world)
+{
+	loop_world = world;
+	out->ctx = nullptr;
+	out->exchange = loop_exchange;
+	out->allgather = loop_allgather;
+	out->allreduce_sum = loop_allreduce;
+}
 
 void cedar_amd_dist3_rank_grid(int world, int pgrid[3])
 {

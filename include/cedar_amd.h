@@ -354,6 +354,9 @@ typedef struct {
 	int (*allgather)(void *ctx, const real_t *send, real_t *recv, size_t count);
 	int (*allreduce_sum)(void *ctx, double *host_values, int n);
 } cedar_amd_transport;
+/* a transport that talks to itself (device-to-device copies in place of send / receive): one rank of a `world`-rank grid
+ * on a single GPU, for measuring what a rank costs beside its messages; ghost values are meaningless */
+void cedar_amd_transport_loopback(cedar_amd_transport *out, int world);
 typedef struct cedar_amd_dist3 cedar_amd_dist3;
 /* the rank grid used when pgrid is NULL: 1x1xN z slabs up to 4 ranks, 2x2x2 for 8 (BASELINE config 5), else the most
  * cubic factorisation */

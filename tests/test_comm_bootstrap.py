@@ -45,3 +45,47 @@ def test_unique_id_reaches_every_rank():
     if blocker:
         blocker.close()
     assert all(got[r] == bytes(range(128)) for r in range(world))
+
+
+def _job_worker(rank, world, port, payload_byte, delay, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    time.sleep(delay)
+    from cedar_amd.comm import bootstrap_bytes
+    payload = bytes([payload_byte]) * 128 if rank == 0 else None
+    q.put((port, rank, bootstrap_bytes(payload, rank, world, timeout=60.0)))
+
+
+def test_two_jobs_on_neighbouring_ports_do_not_cross():
+    """two jobs whose MASTER_PORTs differ by one scan overlapping candidate ports; job B's clients are up before their
+    own rank 0 and reach job A's server first: the handshake carries a job tag (MASTER_PORT, world size, run id), so A
+    neither answers nor counts them and every rank ends with its own job's payload"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    base = s.getsockname()[1]
+    s.close()
+    # job A's first candidate (base + 1) is taken, so its rank 0 serves on base + 2 = job B's FIRST candidate
+    blocker = socket.socket()
+    try:
+        blocker.bind(("127.0.0.1", base + 1))
+        blocker.listen(1)
+    except OSError:
+        blocker = None
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    jobs = [(base, 0xA1, {0: 0.0, 1: 0.3, 2: 0.6}), (base + 1, 0xB2, {0: 1.5, 1: 0.0, 2: 0.1})]
+    ps = [ctx.Process(target=_job_worker, args=(r, world, port, byte, delays[r], q))
+          for port, byte, delays in jobs for r in range(world)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in ps:
+        p.join(30)
+    if blocker:
+        blocker.close()
+    want = {base: bytes([0xA1]) * 128, base + 1: bytes([0xB2]) * 128}
+    assert len(got) == 2 * world
+    for port, rank, payload in got:
+        assert payload == want[port], (port, rank)

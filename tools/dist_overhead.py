@@ -67,6 +67,16 @@ def run(f, k):
 host, total = run(lambda: ds.vcycle(x, b), 5)
 print(json.dumps({"n": n, "solver": "DistSolver3, one rank of %dx%dx%d%s" % (pg + (" (self-talking mock)" if world > 1 else "",)),
                   "levels_distributed": len(ds.levels), "overlap_min": overlap_min, "host_ms_per_vcycle": host, "ms_per_vcycle": total}), flush=True)
+# the same rank of the same grid on the native driver (cedar_amd_dist3_*, orchestration below the C ABI)
+from cedar_amd.dist3 import DistSolver3 as Native
+A2 = be.zeros((14,) + g)
+capi.lib.cedar_amd_gallery(112, A2.ptr, b.ptr, n, n, n, pp)
+dn = Native("loopback", topo.rank, world, A2, pgrid=pg, overlap_min=overlap_min)
+xn = be.zeros(g)
+host, total = run(lambda: dn.vcycle(xn, b), 5)
+print(json.dumps({"n": n, "solver": "cedar_amd_dist3 (native driver), one rank of %dx%dx%d%s" % (pg + (" (loop-back transport)" if world > 1 else "",)),
+                  "overlap_min": overlap_min, "host_ms_per_vcycle": host, "ms_per_vcycle": total}), flush=True)
+dn.close()
 s = capi.Solver(A, share_operator=True)
 xs = be.zeros(g)
 host, total = run(lambda: capi.lib.cedar_amd_solver_vcycle(s.h, xs.ptr, b.ptr), 5)
