@@ -335,8 +335,13 @@ void visit_small(int pre, const real_t *so, const real_t *qf, real_t *q, real_t 
                  int II, int JJ, int nstncl, int kind, int nsweeps, const real_t *ci, real_t *cb, real_t *cx, int IIC, int JJC,
                  hipStream_t st, Batch bf, Batch bc)
 {
-	static bool attr = false;
-	if (!attr) { // 121 KB for a 66 x 66 level with line relaxation
+	// per DEVICE: the attribute belongs to the function on the current device, and a process may switch devices
+	// (cedar_amd_set_device); 121 KB for a 66 x 66 level with line relaxation
+	static bool attr_dev[64] = {false};
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	bool &attr = attr_dev[dev_ & 63];
+	if (!attr) {
 		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)visit_pre_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)visit_pre_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)visit_post_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -391,8 +396,11 @@ void relax_lines_small(const real_t *so, const real_t *qf, real_t *q, const real
 {
 	if (nsweeps <= 0) return;
 	const size_t shm = ((size_t)II * JJ + 3 * (size_t)SMALL_MAX * LP) * sizeof(real_t);
-	static bool attr = false;
-	if (!attr) { // 86 KB for a 66 x 66 level
+	static bool attr_dev[64] = {false}; // per device, see visit_small; 86 KB for a 66 x 66 level
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	bool &attr = attr_dev[dev_ & 63];
+	if (!attr) {
 		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)lines_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)lines_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 		attr = true;

@@ -650,13 +650,13 @@ static cedar_amd_solver *solver_create(int nd, len_t nx, len_t ny, len_t nz, int
 	if (nd == 3 && s->st.ibc) {
 		const int c = s->st.ibc;
 		const bool px = c == 2 || c == 3 || c == 6 || c == 8, py = c == 1 || c == 3 || c == 7 || c == 8, pz = c >= 5;
-		bool ok = (size_t)s->nabd2 <= 8192; // dense factor: n^2 doubles, one workgroup
+		bool ok = (size_t)s->nabd2 <= 2048; // dense factor in ONE workgroup: n^2 doubles, n^3/3 flops (2048: ~3 GFlop, about a second)
 		for (int l = 0; l + 1 < nlev; l++)
 			ok = ok && !(px && (s->lv[l].nx & 1)) && !(py && (s->lv[l].ny & 1)) && !(pz && (s->lv[l].nz & 1));
 		if (!ok) {
 			char msg[] = "cedar_amd_solver_create: 3D periodic boundary conditions need an even extent in every periodic "
 			             "direction on each level that is coarsened (choose the extents or num_levels accordingly) and at "
-			             "most 8192 unknowns on the coarsest level; no solver created";
+			             "most 2048 unknowns on the coarsest level (it is factored densely by one workgroup: use more levels); no solver created";
 			print_error(msg);
 			cedar_amd_solver_destroy(s); // releases the levels allocated so far
 			return nullptr;
