@@ -28,7 +28,8 @@ Extra keys in the JSON line:
                not be the luck of the first allocation.  --allocations 1: the first allocation only.
 Multi-GPU (N > 1): one process per GPU.  Started as the driver does (torch.distributed.run sets RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_*) every process is a rank; started bare (`python bench.py --gpus N`) the parent spawns N fresh rank
-processes before it touches a GPU itself.  The 3D workload runs without torch: halo, norms and coarse gather are RCCL
+processes before it touches a GPU itself.  No workload imports torch: the distributed cycles run below the C ABI
+(cedar_amd_dist3_* / cedar_amd_dist2_*) and halo, norms and coarse gather are RCCL
 calls issued by libcedar_amd.so (cedar_amd/comm.py).  N GPUs requested but fewer visible is an error.
 """
 import argparse
@@ -284,11 +285,6 @@ def main():
     # (2 and 4 GPUs run z slabs: a whole k-parity -- the plane-fused kernel -- between two exchanges)
     n = args.size or n_default
 
-    use_torch = world > 1 and nd == 2  # the 2D multi-GPU solver still runs on torch tensors (cedar_amd/dist2d.py)
-    if use_torch:
-        # torch bundles its own libamdhip64.so.7: it must be the first one mapped in a process that uses both torch
-        # and libcedar_amd.so; the 3D path below never imports torch
-        import torch  # noqa: F401
     from cedar_amd import capi
     ndev = capi.device_count()
     if ndev < 1:
@@ -296,19 +292,11 @@ def main():
     if world > 1 and ndev < world and not rehearsal:
         raise SystemExit("bench.py: %d GPUs requested, %d visible" % (world, ndev))
 
-    dist, comm = None, None
+    comm = None
     if world > 1:
         local_rank = local_rank % ndev  # rehearsal on a one-GPU box: the ranks share the card
     capi.set_device(local_rank)
-    if use_torch:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif world > 1:
+    if world > 1:
         from cedar_amd.comm import NativeComm, SocketComm
         comm = SocketComm(rank, world) if rehearsal else NativeComm(rank, world)
 
@@ -345,13 +333,11 @@ def main():
                 dsolver = NativeDist3(comm, rank, world, A, pgrid=topo.p)
             xt = be.zeros(g)
         else:
-            # 2D workloads: n^2 per GPU of a (px n) x (py n) global grid, cedar_amd/dist2d.py.  The
-            # synthetic operators are host generators of the whole grid: every rank builds it and keeps its block.
+            # 2D workloads: n^2 per GPU of a (px n) x (py n) global grid on the native driver
+            # (cedar_amd_dist2_*, cedar_amd/csrc/dist2.cpp): no torch in the rank process.  The synthetic operators are host
+            # generators of the whole grid: every rank builds it and keeps its block.
             import problems as pb
-            import torch
-            from cedar_amd._torch_dist import GpuBackend
-            from cedar_amd.dist2d import DistSolver2, rank_grid2
-            dev = torch.device("cuda", local_rank)
+            from cedar_amd.dist3 import DistSolver2 as NativeDist2, rank_grid2
             px, py = rank_grid2(world)
             if 5.0 * (px * n + 2) * (py * n + 2) * 8 > 12e9:
                 raise SystemExit("bench.py: the host generator of this 2D workload is too large for %d GPUs at %d^2 per GPU; "
@@ -362,11 +348,11 @@ def main():
             ci, cj = topo.coord[:2]
             sl = (slice(cj * n, cj * n + n + 2), slice(ci * n, ci * n + n + 2))
             m = pb.interior_mask((n + 2, n + 2)).astype(np.float64)
-            A = torch.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m).to(dev)
-            bt = torch.from_numpy(np.ascontiguousarray(gb[sl]) * m).to(dev)
+            A = capi.DeviceArray.from_numpy(np.ascontiguousarray(gso[(slice(None),) + sl]) * m)
+            bt = capi.DeviceArray.from_numpy(np.ascontiguousarray(gb[sl]) * m)
             del gso, gb
-            dsolver = DistSolver2(GpuBackend(dev), topo, A, relax=relax)
-            xt = torch.zeros_like(bt)
+            dsolver = NativeDist2(comm, rank, world, A, pgrid=(px, py), relax=relax)
+            xt = capi.DeviceArray(bt.shape)
         so = b = x = None
 
         class _S:  # minimal adapter so that the timing code below is shared
@@ -380,7 +366,7 @@ def main():
                 if hasattr(dsolver, "time_relax"):
                     return dsolver.time_relax(xt, bt, k)
                 from cedar_amd.comm import EventTimer
-                t = EventTimer()  # HIP events on the library's stream (the null stream torch shares in the 2D case)
+                t = EventTimer()  # HIP events on the library's stream
                 for i in range(k):
                     dsolver._smooth(dsolver.levels[0], xt, bt, i & 1, 1)
                 return t.stop()
@@ -399,9 +385,7 @@ def main():
 
     def barrier():
         capi.lib.cedar_amd_device_sync()
-        if dist is not None:
-            dist.barrier()
-        elif comm is not None:
+        if comm is not None:
             comm.barrier()
         capi.lib.cedar_amd_device_sync()
 
@@ -413,12 +397,7 @@ def main():
         solver.vcycle(x, b)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    elif comm is not None:
+    if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
 
     # dominant kernel: the level-0 relax sweep, HIP events on the library's stream
@@ -515,8 +494,7 @@ def main():
                        "domain decomposition %s ranks, %s per GPU, halo exchange over %s" %
                        ("x".join(map(str, topo.p[:nd])),
                         "x".join(str(int(v)) for v in ln) if nd == 3 else "%d^2" % n,
-                        comm.name if comm is not None else
-                        ("RCCL (torch.distributed)" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)"))},
+                        comm.name)},
             "roofline": roofline,
             # device-side interp + Galerkin + relax set-up + solve copies, host-timed around solver creation.  Quoted: the
             # MINIMUM over the solver creations of this process.  A creation that maps device memory the process has not
@@ -544,10 +522,7 @@ def main():
         print(json.dumps(out), flush=True)
     if solver is not None:
         solver.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    elif comm is not None:
+    if comm is not None:
         comm.barrier()
         comm.close()
 

@@ -17,39 +17,13 @@
 // Transport: the library's RCCL communicator (comm.cpp) -- or a caller-supplied table of three functions, the
 // counterpart of the reference's halo_exchanger plug-in (include/cedar/kernel.h:25-37, kernel_manager::add_halo):
 // the one-GPU rehearsal hands in a host-staged transport so that several ranks can share a card (RCCL refuses that).
-#include "../../include/cedar_amd.h"
-#include "common.h"
-#include "stage.h"
+#include "dist_common.h"
 #include <cmath>
-#include <cstring>
-#include <map>
-#include <utility>
-#include <vector>
 
 using namespace cedar_amd;
+using namespace cedar_amd::dist;
 
 namespace {
-
-struct HaloEntry {
-	int o[3];
-	int peer;
-	int sbox[6], rbox[6];
-	size_t size, off;
-};
-
-struct HaloGroup {
-	std::vector<int> idx;          // entries of the group
-	std::vector<int> sboxes, rboxes; // 6 ints per entry
-	std::vector<unsigned long long> offs;
-};
-
-struct Halo {
-	int n[3] = {0, 0, 0};
-	std::vector<HaloEntry> nb;
-	size_t total = 0;
-	HaloGroup grp[3]; // 0 = every neighbour, 1 = across an x face / edge / corner, 2 = the others (y/z)
-	std::map<long, std::pair<real_t *, real_t *>> bufs;
-};
 
 struct DLevel {
 	int n[3] = {0, 0, 0};
@@ -60,28 +34,9 @@ struct DLevel {
 	Halo halo;
 };
 
-real_t *dmalloc(size_t n)
-{
-	return static_cast<real_t *>(cedar_amd_malloc((n ? n : 1) * sizeof(real_t))); // cleared
-}
-
-// index range along one axis of extent n+2 for neighbour offset d (cedar_amd/dist.py _rng): d != 0: send = the owned
-// layer next to that side, recv = the ghost layer; d == 0: the owned cells plus the ghost cell on every side that is a
-// PHYSICAL boundary (those ghosts carry values the serial kernels compute for even extents)
-void rng(int d, int n, bool recv, bool has_minus, bool has_plus, int &lo, int &hi)
-{
-	if (d == 0) { lo = has_minus ? 1 : 0; hi = has_plus ? n + 1 : n + 2; }
-	else if (d < 0) { lo = recv ? 0 : 1; hi = lo + 1; }
-	else { lo = recv ? n + 1 : n; hi = lo + 1; }
-}
-
 } // namespace
 
-struct cedar_amd_dist3 {
-	cedar_amd_comm *comm = nullptr;
-	cedar_amd_transport tp{};
-	bool has_tp = false;
-	int rank = 0, world = 1, p[3] = {1, 1, 1}, coord[3] = {0, 0, 0};
+struct cedar_amd_dist3 : RankCtx {
 	int pre = 2, post = 1, max_iter = 10, min_coarse = 3, overlap_min = 96, agglomerate_below = 64;
 	double tol = 1e-8;
 	int sides = 0;
@@ -92,171 +47,9 @@ struct cedar_amd_dist3 {
 	real_t *gA = nullptr, *gx = nullptr, *gb = nullptr, *cs_tmp = nullptr;
 	cedar_amd_solver *serial = nullptr;
 	std::map<long, std::pair<real_t *, real_t *>> gbuf;
-	void *side = nullptr; // non-blocking side stream of the overlapped y/z halo
-	real_t *scal = nullptr, *red = nullptr;
-	bool pending = false;
 };
 
 namespace {
-
-bool has_nb(const cedar_amd_dist3 *d, int dim, int side) { return d->coord[dim] + side >= 0 && d->coord[dim] + side < d->p[dim]; }
-int rank_of(const cedar_amd_dist3 *d, int ci, int cj, int ck) { return ci + d->p[0] * (cj + d->p[1] * ck); }
-
-// ---- transport
-int tp_exchange(cedar_amd_dist3 *d, int ns, const int *speer, const real_t *const *sbuf, const size_t *scount,
-                int nr, const int *rpeer, real_t *const *rbuf, const size_t *rcount)
-{
-	if (ns + nr == 0) return 0;
-	if (d->has_tp) return d->tp.exchange(d->tp.ctx, ns, speer, sbuf, scount, nr, rpeer, rbuf, rcount);
-	return cedar_amd_comm_exchange(d->comm, ns, speer, sbuf, scount, nr, rpeer, rbuf, rcount);
-}
-
-void tp_allgather(cedar_amd_dist3 *d, const real_t *send, real_t *recv, size_t count)
-{
-	if (d->world == 1) {
-		cedar_amd_memcpy_d2d(recv, send, count * sizeof(real_t));
-		return;
-	}
-	const int rc = d->has_tp ? d->tp.allgather(d->tp.ctx, send, recv, count) : cedar_amd_comm_allgather(d->comm, send, recv, count);
-	if (rc) { char m[] = "cedar_amd_dist3: all-gather failed"; print_error(m); }
-}
-
-double tp_allreduce_sum(cedar_amd_dist3 *d, double v)
-{
-	if (d->world == 1) return v;
-	if (d->has_tp) {
-		if (d->tp.allreduce_sum(d->tp.ctx, &v, 1)) { char m[] = "cedar_amd_dist3: all-reduce failed"; print_error(m); }
-		return v;
-	}
-	cedar_amd_memcpy_h2d(d->scal, &v, sizeof(double));
-	if (cedar_amd_comm_allreduce_sum(d->comm, d->scal, 1)) { char m[] = "cedar_amd_dist3: all-reduce failed"; print_error(m); }
-	cedar_amd_memcpy_d2h(&v, d->scal, sizeof(double));
-	return v;
-}
-
-// ---- halo (cedar_amd/dist.py Halo)
-void halo_init(cedar_amd_dist3 *d, Halo &h, const int n[3])
-{
-	for (int t = 0; t < 3; t++) h.n[t] = n[t];
-	bool hm[3], hp[3];
-	for (int t = 0; t < 3; t++) { hm[t] = has_nb(d, t, -1); hp[t] = has_nb(d, t, +1); }
-	size_t off = 0;
-	// neighbours in the order of the sorted offsets (dx, dy, dz), as dist.py: both ends of a message agree on the layout
-	for (int dx = -1; dx <= 1; dx++)
-		for (int dy = -1; dy <= 1; dy++)
-			for (int dz = -1; dz <= 1; dz++) {
-				if (!dx && !dy && !dz) continue;
-				const int c[3] = {d->coord[0] + dx, d->coord[1] + dy, d->coord[2] + dz};
-				if (c[0] < 0 || c[0] >= d->p[0] || c[1] < 0 || c[1] >= d->p[1] || c[2] < 0 || c[2] >= d->p[2]) continue;
-				HaloEntry e;
-				e.o[0] = dx; e.o[1] = dy; e.o[2] = dz;
-				e.peer = rank_of(d, c[0], c[1], c[2]);
-				int lo[3], hi[3];
-				for (int t = 0; t < 3; t++) rng(e.o[t], n[t], false, hm[t], hp[t], lo[t], hi[t]);
-				for (int t = 0; t < 3; t++) { e.sbox[t] = lo[t]; e.sbox[3 + t] = hi[t] - lo[t]; }
-				for (int t = 0; t < 3; t++) rng(e.o[t], n[t], true, hm[t], hp[t], lo[t], hi[t]);
-				for (int t = 0; t < 3; t++) { e.rbox[t] = lo[t]; e.rbox[3 + t] = hi[t] - lo[t]; }
-				e.size = (size_t)e.sbox[3] * e.sbox[4] * e.sbox[5];
-				e.off = off;
-				off += e.size;
-				h.nb.push_back(e);
-			}
-	h.total = off;
-	for (int g = 0; g < 3; g++) {
-		HaloGroup &G = h.grp[g];
-		for (size_t i = 0; i < h.nb.size(); i++) {
-			const HaloEntry &e = h.nb[i];
-			if ((g == 1 && e.o[0] == 0) || (g == 2 && e.o[0] != 0)) continue;
-			G.idx.push_back((int)i);
-			for (int t = 0; t < 6; t++) { G.sboxes.push_back(e.sbox[t]); G.rboxes.push_back(e.rbox[t]); }
-			G.offs.push_back((unsigned long long)e.off);
-		}
-	}
-}
-
-std::pair<real_t *, real_t *> &halo_bufs(Halo &h, long key, size_t count)
-{
-	auto it = h.bufs.find(key);
-	if (it == h.bufs.end()) it = h.bufs.emplace(key, std::make_pair(dmalloc(count), dmalloc(count))).first;
-	return it->second;
-}
-
-// fill every ghost cell owned by a neighbour of the group: pack (one launch) -> one grouped exchange -> unpack
-void halo_exchange(cedar_amd_dist3 *d, DLevel &L, real_t *arr, int nplanes, int group)
-{
-	Halo &h = L.halo;
-	HaloGroup &G = h.grp[group];
-	if (G.idx.empty()) return;
-	auto &bp = halo_bufs(h, nplanes, h.total * (size_t)nplanes);
-	real_t *sb = bp.first, *rb = bp.second;
-	const int nbx = (int)G.idx.size();
-	cedar_amd_box_copy(arr, L.II, L.JJ, L.KK, nplanes, nbx, G.sboxes.data(), G.offs.data(), sb, 0);
-	int peer[26];
-	const real_t *sp[26];
-	real_t *rp[26];
-	size_t cnt[26];
-	for (int i = 0; i < nbx; i++) {
-		const HaloEntry &e = h.nb[G.idx[i]];
-		peer[i] = e.peer;
-		sp[i] = sb + e.off * (size_t)nplanes;
-		rp[i] = rb + e.off * (size_t)nplanes;
-		cnt[i] = e.size * (size_t)nplanes;
-	}
-	if (tp_exchange(d, nbx, peer, sp, cnt, nbx, peer, rp, cnt)) { char m[] = "cedar_amd_dist3: halo exchange failed"; print_error(m); }
-	cedar_amd_box_copy(arr, L.II, L.JJ, L.KK, nplanes, nbx, G.rboxes.data(), G.offs.data(), rb, 1);
-}
-
-// x faces only (owned j,k): to_minus: first owned column to the -x neighbour, the +x neighbour's into the high ghost
-// column (UP order); else the mirror image.  Returns true if a column was received.
-bool halo_exchange_x(cedar_amd_dist3 *d, DLevel &L, real_t *arr, bool to_minus)
-{
-	const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
-	const int send_to = to_minus ? -1 : +1, send_col = to_minus ? 1 : nx, recv_from = -send_to, recv_col = to_minus ? nx + 1 : 0;
-	auto &bp = halo_bufs(L.halo, to_minus ? -1 : -2, (size_t)ny * nz);
-	const unsigned long long zero = 0;
-	int speer = 0, rpeer = 0, ns = 0, nr = 0;
-	const real_t *sp = bp.first;
-	real_t *rp = bp.second;
-	size_t cnt = (size_t)ny * nz;
-	if (has_nb(d, 0, send_to)) {
-		const int box[6] = {send_col, 1, 1, 1, ny, nz};
-		cedar_amd_box_copy(arr, L.II, L.JJ, L.KK, 1, 1, box, &zero, bp.first, 0);
-		speer = rank_of(d, d->coord[0] + send_to, d->coord[1], d->coord[2]);
-		ns = 1;
-	}
-	if (has_nb(d, 0, recv_from)) {
-		rpeer = rank_of(d, d->coord[0] + recv_from, d->coord[1], d->coord[2]);
-		nr = 1;
-	}
-	if (tp_exchange(d, ns, &speer, &sp, &cnt, nr, &rpeer, &rp, &cnt)) { char m[] = "cedar_amd_dist3: x-face exchange failed"; print_error(m); }
-	if (nr) {
-		const int box[6] = {recv_col, 1, 1, 1, ny, nz};
-		cedar_amd_box_copy(arr, L.II, L.JJ, L.KK, 1, 1, box, &zero, bp.second, 1);
-	}
-	return nr != 0;
-}
-
-// ---- side stream: work issued between side_begin / side_end goes to the side stream, ordered after everything
-// already queued on the main stream; side_wait orders the main stream after it
-void *side_begin(cedar_amd_dist3 *d)
-{
-	if (!d->side) d->side = cedar_amd_stream_create();
-	void *main_st = cedar_amd_get_stream();
-	cedar_amd_stream_wait(d->side, main_st);
-	cedar_amd_set_stream(d->side);
-	return main_st;
-}
-void side_end(cedar_amd_dist3 *d, void *main_st)
-{
-	cedar_amd_set_stream(main_st);
-	d->pending = true;
-}
-void side_wait(cedar_amd_dist3 *d)
-{
-	if (!d->pending) return;
-	cedar_amd_stream_wait(cedar_amd_get_stream(), d->side);
-	d->pending = false;
-}
 
 // ---- gather of a level onto every rank (replaces the reference's redistribution solver)
 void gather_into(cedar_amd_dist3 *d, real_t *local, int lII, int lJJ, int lKK, int nplanes, real_t *glob)
@@ -294,7 +87,7 @@ void smooth(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int updown, int
 		if (L.nst == 4) {
 			for (int c = 0; c < 2; c++) {
 				cedar_amd_relax3_colour7(L.A, b, x, L.sor, L.II, L.JJ, L.KK, up ? c : 1 - c);
-				halo_exchange(d, L, x, 1, 0);
+				halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 0);
 			}
 			continue;
 		}
@@ -309,11 +102,11 @@ void smooth(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int updown, int
 					side_wait(d);
 					cedar_amd_relax3_planes(L.A, b, x, L.sor, L.II, L.JJ, L.KK, kb, up, 2 | (d->sides << 4));
 					void *m = side_begin(d);
-					halo_exchange(d, L, x, 1, 0);
+					halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 0);
 					side_end(d, m);
 				} else {
 					cedar_amd_relax3_planes(L.A, b, x, L.sor, L.II, L.JJ, L.KK, kb, up, 0);
-					halo_exchange(d, L, x, 1, 0);
+					halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 0);
 				}
 			}
 			continue;
@@ -330,15 +123,15 @@ void smooth(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int updown, int
 				cedar_amd_relax3_pass_part(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jb, kb, up, 0);
 			if (d->p[0] > 1) {
 				// the second i-colour of the column next to an x neighbour needs that neighbour's fresh first colour
-				if (halo_exchange_x(d, L, x, up)) cedar_amd_relax3_fixup(L.A, b, x, L.sor, L.II, L.JJ, L.KK, up ? L.n[0] : 1, jb, kb);
+				if (halo_exchange_x(d, L.halo, L.II, L.JJ, L.KK, x, up)) cedar_amd_relax3_fixup(L.A, b, x, L.sor, L.II, L.JJ, L.KK, up ? L.n[0] : 1, jb, kb);
 			}
 			if (L.overlap) {
-				halo_exchange(d, L, x, 1, 1); // x ghosts are read by every row of the next pass: in order
+				halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 1); // x ghosts are read by every row of the next pass: in order
 				void *m = side_begin(d);
-				halo_exchange(d, L, x, 1, 2);
+				halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 2);
 				side_end(d, m);
 			} else
-				halo_exchange(d, L, x, 1, 0);
+				halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 0);
 		}
 	}
 	side_wait(d);
@@ -364,13 +157,13 @@ void cycle(cedar_amd_dist3 *d, int l, real_t *x, real_t *b)
 	DLevel &L = d->lv[l], &K = d->lv[l + 1];
 	smooth(d, L, x, b, BMG_DOWN, d->pre);
 	BMG3_SymStd_residual(1, 1, L.nst == 4, x, b, L.A, L.res, L.II, L.JJ, L.KK, L.nst);
-	halo_exchange(d, L, L.res, 1, 0);
+	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, L.res, 1, 0);
 	BMG3_SymStd_restrict(L.res, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, 0);
 	cedar_amd_memset(K.x, 0, K.npts * sizeof(real_t));
 	if (l + 1 == (int)d->lv.size() - 1) coarse_solve(d, K, K.x, K.b);
 	else cycle(d, l + 1, K.x, K.b);
 	BMG3_SymStd_interp_add(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, L.nst, 0);
-	halo_exchange(d, L, x, 1, 0);
+	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 0);
 	smooth(d, L, x, b, BMG_UP, d->post);
 }
 
@@ -391,16 +184,16 @@ void setup(cedar_amd_dist3 *d)
 {
 	const int lo[3] = {has_nb(d, 0, -1) ? 2 : 3, has_nb(d, 1, -1) ? 2 : 3, has_nb(d, 2, -1) ? 2 : 3};
 	DLevel &L0 = d->lv[0];
-	halo_exchange(d, L0, L0.A, L0.nst, 0);
+	halo_exchange(d, L0.halo, L0.II, L0.JJ, L0.KK, L0.A, L0.nst, 0);
 	for (size_t l = 0; l + 1 < d->lv.size(); l++) {
 		DLevel &F = d->lv[l], &K = d->lv[l + 1];
 		for (int phase = 0; phase < 3; phase++) {
 			cedar_amd_setup_interp3_phase(F.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, F.nst == 4, F.nst, phase, lo[0], lo[1], lo[2]);
-			halo_exchange(d, K, K.P, 26, 0);
+			halo_exchange(d, K.halo, K.II, K.JJ, K.KK, K.P, 26, 0);
 		}
 		if (F.nst == 4) BMG3_SymStd_SETUP_ITLI07_ex(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, 0);
 		else BMG3_SymStd_SETUP_ITLI27_ex(F.A, K.A, K.P, F.II, F.JJ, F.KK, K.II, K.JJ, K.KK, 0);
-		halo_exchange(d, K, K.A, 14, 0);
+		halo_exchange(d, K.halo, K.II, K.JJ, K.KK, K.A, 14, 0);
 		BMG3_SymStd_SETUP_recip(F.A, F.sor, F.II, F.JJ, F.KK, F.nst, 2);
 		// slab decomposition: its sweeps are the plane-fused passes of the single-GPU solver, which read the
 		// row-interleaved solve copy where one is registered (worth 7 %; neutral on rank grids with an x / y split)
@@ -613,7 +406,7 @@ int cedar_amd_dist3_solve(cedar_amd_dist3 *d, real_t *b, real_t *x, real_t *rel)
 {
 	if (!d) return 0;
 	DLevel &L = d->lv[0];
-	halo_exchange(d, L, x, 1, 0);
+	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 0);
 	BMG3_SymStd_residual(1, 1, L.nst == 4, x, b, L.A, L.res, L.II, L.JJ, L.KK, L.nst);
 	const double r0 = norm(d, L, L.res);
 	rel[0] = r0;

@@ -1,5 +1,5 @@
-"""The domain-decomposed 3D solver as the library runs it: `cedar_amd_dist3_*` (include/cedar_amd.h section 4,
-cedar_amd/csrc/dist3.cpp).  The whole cycle -- sweeps by row class, halo exchanges on the main and the side stream,
+"""The domain-decomposed solvers as the library runs them: `cedar_amd_dist3_*` / `cedar_amd_dist2_*` (include/cedar_amd.h
+sections 4 and 4b, cedar_amd/csrc/dist3.cpp, dist2.cpp).  The whole cycle -- sweeps by row class, halo exchanges on the main and the side stream,
 x-face fix-ups, gathered coarse levels, norms -- is orchestrated in compiled code below the C ABI; this module only
 hands over the rank's arrays and the transport.
 
@@ -40,6 +40,24 @@ lib.cedar_amd_dist3_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_vo
 lib.cedar_amd_dist3_time_relax.restype = C.c_float
 lib.cedar_amd_dist3_time_relax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 lib.cedar_amd_dist3_rank_grid.argtypes = [C.c_int, C.POINTER(C.c_int)]
+
+
+lib.cedar_amd_dist2_create.restype = C.c_void_p
+lib.cedar_amd_dist2_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p,
+                                       C.c_uint, C.c_uint, C.c_int, C.c_void_p, C.c_int]
+lib.cedar_amd_dist2_destroy.argtypes = [C.c_void_p]
+lib.cedar_amd_dist2_nlevels.argtypes = [C.c_void_p]
+lib.cedar_amd_dist2_vcycle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+lib.cedar_amd_dist2_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.cedar_amd_dist2_time_relax.restype = C.c_float
+lib.cedar_amd_dist2_time_relax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.cedar_amd_dist2_rank_grid.argtypes = [C.c_int, C.POINTER(C.c_int)]
+
+
+def rank_grid2(world):
+    p = (C.c_int * 2)()
+    lib.cedar_amd_dist2_rank_grid(world, p)
+    return tuple(p)
 
 
 def rank_grid(world):
@@ -133,6 +151,61 @@ class DistSolver3:
     def close(self):
         if self.h:
             lib.cedar_amd_dist3_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class DistSolver2:
+    """cdr2::mpi::solver on one rank's GPU (cedar_amd_dist2_*, cedar_amd/csrc/dist2.cpp): point relaxation or zebra line
+    relaxation with the lines cut by the ranks; `A_local` = capi.DeviceArray (nst, ny+2, nx+2)"""
+
+    def __init__(self, comm, rank, world, A_local, pgrid=None, relax="point", nrelax_pre=2, nrelax_post=1, min_coarse=3,
+                 max_iter=10, tol=1e-8, agglomerate_below=64):
+        self.comm, self.rank, self.world = comm, rank, world
+        self._A = A_local
+        nst = A_local.shape[0]
+        ny, nx = (int(v) - 2 for v in A_local.shape[1:])
+        st = capi.Settings(capi.RELAX[relax], nrelax_pre, nrelax_post, -1, max_iter, tol, min_coarse, 0, 0)
+        capi.plane_settings(st, None)
+        self.max_iter = max_iter
+        self.p = tuple(pgrid) if pgrid else rank_grid2(world)
+        pg = (C.c_int * 2)(*self.p)
+        handle, table = None, None
+        if comm == "loopback":
+            self._tab = _Transport()
+            lib.cedar_amd_transport_loopback(C.byref(self._tab), world)
+            table = C.byref(self._tab)
+        elif isinstance(comm, NativeComm):
+            handle = comm.h
+        elif comm is not None and world > 1:
+            self._tab, self._keep = _table_from(comm)
+            table = C.byref(self._tab)
+        self.h = lib.cedar_amd_dist2_create(handle, table, rank, world, pg, A_local.ptr, nx, ny, nst, C.byref(st),
+                                            agglomerate_below)
+        if not self.h:
+            raise RuntimeError("cedar_amd_dist2_create failed")
+        self.nlev_global = lib.cedar_amd_dist2_nlevels(self.h)
+        self.coord = (rank % self.p[0], rank // self.p[0])
+
+    def vcycle(self, x, b):
+        lib.cedar_amd_dist2_vcycle(self.h, x.ptr, b.ptr)
+
+    def solve(self, b, x):
+        rel = np.zeros(self.max_iter + 1)
+        n = lib.cedar_amd_dist2_solve(self.h, b.ptr, x.ptr, rel.ctypes.data)
+        return [float(v) for v in rel[: n + 1]]
+
+    def time_relax(self, x, b, n):
+        return float(lib.cedar_amd_dist2_time_relax(self.h, x.ptr, b.ptr, n))
+
+    def close(self):
+        if self.h:
+            lib.cedar_amd_dist2_destroy(self.h)
             self.h = None
 
     def __del__(self):

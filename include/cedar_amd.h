@@ -380,6 +380,25 @@ int cedar_amd_dist3_solve(cedar_amd_dist3 *d, real_t *b_dev, real_t *x_dev, real
 /* n level-0 sweeps (alternating DOWN / UP) with their halo exchanges; elapsed ms by HIP events */
 float cedar_amd_dist3_time_relax(cedar_amd_dist3 *d, real_t *x_dev, real_t *b_dev, int n);
 
+/* ------------------------------------------------------------------ 4b. the domain-decomposed 2D solver
+ * cdr2::mpi::solver of the reference (include/cedar/2d/mpi/solver.h) for Dirichlet problems on a px x py rank grid
+ * (rank = j*px + i), V(pre,post), point relaxation or zebra line relaxation in x, y or both with the lines cut by the
+ * ranks of a row / column of the grid -- the reference's distributed tridiagonal solves
+ * (src/2d/ftn/mpi/BMG2_SymStd_relax_lines_x.f90:163-307, include/cedar/2d/mpi/ml_relax.h) as a chain of segments whose
+ * carries the ranks of a line hand each other (cedar_amd/csrc/dist_lines.hip).  Orchestrated below this ABI
+ * (cedar_amd/csrc/dist2.cpp), no torch in a rank process; transport and arguments as for cedar_amd_dist3_create
+ * (settings->relaxation selects the smoother).  A_local: device array (nstencil = 3 | 5, ny+2, nx+2). */
+typedef struct cedar_amd_dist2 cedar_amd_dist2;
+void cedar_amd_dist2_rank_grid(int world, int pgrid[2]);   /* 1x1, 1x2, 2x2, 2x4: y is split first */
+cedar_amd_dist2 *cedar_amd_dist2_create(cedar_amd_comm *comm, const cedar_amd_transport *transport, int rank, int world,
+                                        const int pgrid[2], real_t *A_local, len_t nx, len_t ny, int nstencil,
+                                        const cedar_amd_settings *settings, int agglomerate_below);
+void cedar_amd_dist2_destroy(cedar_amd_dist2 *d);
+int cedar_amd_dist2_nlevels(const cedar_amd_dist2 *d);
+void cedar_amd_dist2_vcycle(cedar_amd_dist2 *d, real_t *x_dev, real_t *b_dev);
+int cedar_amd_dist2_solve(cedar_amd_dist2 *d, real_t *b_dev, real_t *x_dev, real_t *rel);
+float cedar_amd_dist2_time_relax(cedar_amd_dist2 *d, real_t *x_dev, real_t *b_dev, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,7 +153,7 @@ class GpuBackend:
     """HIP kernels through the C ABI (include/cedar_amd.h) on torch CUDA tensors."""
 
     def __init__(self, device):
-        from . import capi
+        from cedar_amd import capi
         self.capi, self.lib = capi, capi.lib
         self.device = device
         capi.set_device(device.index if device.index is not None else 0)

@@ -32,8 +32,8 @@ import math
 import torch
 import torch.distributed as dist
 
-from ._torch_dist import Halo
-from .dist import Topology
+from _torch_dist import Halo
+from cedar_amd.dist import Topology
 
 DOWN, UP = 0, 1
 

@@ -49,7 +49,7 @@ def _worker(rank, world, port, case, outdir):
     try:
         import problems as pb
         from cedar_amd.dist import Topology
-        from cedar_amd.dist2d import DistSolver2
+        from dist2d_torch import DistSolver2
         from dist_cpu_backend import CpuBackend
         kind, n, pgrid, relax, agg = case
         topo = Topology(rank, world, (pgrid[0], pgrid[1], 1))
