@@ -8,8 +8,7 @@
 #include "../../include/cedar_amd.h"
 #include "../../include/cedar/capi.h"
 #include "../../include/cedar/config.h"
-#include "common.h"
-#include "stage.h"
+#include "dist_common.h"
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -43,13 +42,47 @@ void report(const std::string &msg)
 	print_error(buf.data());
 }
 
-// grid_topo of the reference reduced to what a single rank needs
+// ---- who this process is among the ranks, and how it talks to them
+int g_rank = -1, g_world = -1;
+cedar_amd_comm *g_comm = nullptr;
+cedar_amd_transport g_tp{};
+bool g_has_tp = false;
+
+int env_int(const char *const names[], int n, int dflt)
+{
+	for (int i = 0; i < n; i++)
+		if (const char *e = getenv(names[i])) return atoi(e);
+	return dflt;
+}
+
+void rank_world(int &rank, int &world)
+{
+	static const char *const rk[] = {"RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID"};
+	static const char *const wd[] = {"WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS"};
+	rank = g_rank >= 0 ? g_rank : env_int(rk, 4, 0);
+	world = g_world >= 1 ? g_world : env_int(wd, 4, 1);
+}
+
+// transport of a multi-rank topology: the table handed in, else the RCCL communicator (made once per process)
+bool transport(int rank, int world, cedar_amd_comm *&comm, const cedar_amd_transport *&tp)
+{
+	comm = nullptr; tp = nullptr;
+	if (world == 1) return true;
+	if (g_has_tp) { tp = &g_tp; return true; }
+	if (!g_comm) g_comm = cedar_amd_comm_bootstrap(rank, world);
+	comm = g_comm;
+	return comm != nullptr;
+}
+
+// grid_topo of the reference (src/2d/interface/c/topo.cc:10-66): process grid, this rank's place and extents
 struct topo_t {
 	int nd;
 	unsigned ng[3]; // global interior extents
 	unsigned nl[3]; // local interior extents
 	unsigned is[3]; // 1-based global index of the first local point (src/2d/interface/c/topo.cc:38-45)
 	int nproc[3], coord[3];
+	int rank, world;
+	bool uniform; // every rank owns the same extents (what the domain-decomposed drivers take)
 };
 
 struct op_t {
@@ -58,12 +91,17 @@ struct op_t {
 	std::vector<real_t> so; // Cedar layout: (nst, [KK,] JJ, II), i fastest
 	real_t *dso = nullptr, *dx = nullptr, *db = nullptr;
 	bool dirty = true;
+	cedar_amd::dist::Halo *halo = nullptr; // multi-rank: ghost exchange of x for operator_apply
 	size_t pts() const { return (size_t)(topo.nl[0] + 2) * (topo.nl[1] + 2) * (topo.nd == 3 ? topo.nl[2] + 2 : 1); }
 	~op_t()
 	{
 		cedar_amd_free(dso);
 		cedar_amd_free(dx);
 		cedar_amd_free(db);
+		if (halo) {
+			for (auto &kv : halo->bufs) { cedar_amd_free(kv.second.first); cedar_amd_free(kv.second.second); }
+			delete halo;
+		}
 	}
 	void upload()
 	{
@@ -79,28 +117,55 @@ struct op_t {
 
 struct slv_t {
 	op_t *op;
-	cedar_amd_solver *h;
+	cedar_amd_solver *h = nullptr;
+	cedar_amd_dist2 *d2 = nullptr;
+	cedar_amd_dist3 *d3 = nullptr;
 	cedar_amd_settings st;
 	std::vector<real_t> xg, bg, rel;
 };
 
+// rank context of a topology for the shared halo machinery (dist_common.h)
+bool rank_ctx(const topo_t &t, cedar_amd::dist::RankCtx &c)
+{
+	cedar_amd_comm *comm;
+	const cedar_amd_transport *tp;
+	if (!transport(t.rank, t.world, comm, tp)) return false;
+	c.comm = comm;
+	if (tp) { c.tp = *tp; c.has_tp = true; }
+	c.rank = t.rank; c.world = t.world;
+	for (int d = 0; d < 3; d++) { c.p[d] = t.nproc[d]; c.coord[d] = t.coord[d]; }
+	return true;
+}
+
 topo_t *make_topo(int nd, const unsigned ng[3], unsigned *const ln[3], const int np[3])
 {
-	for (int d = 0; d < nd; d++) {
-		if (np[d] != 1) {
-			report("bmg_topo_create: this library runs one rank per GPU; the C interface serves nproc = 1 per direction "
-			       "(multi-GPU runs use the domain-decomposed driver, DESIGN.md section 7)");
-			return nullptr;
-		}
+	int rank, world;
+	rank_world(rank, world);
+	int nproc = 1;
+	for (int d = 0; d < nd; d++) nproc *= np[d] < 1 ? 1 : np[d];
+	if (nproc != world || rank >= world) {
+		char buf[240];
+		snprintf(buf, sizeof(buf), "bmg_topo_create: the process grid has %d ranks but the launcher started %d (this is rank %d: RANK / "
+		         "WORLD_SIZE, PMI_*, OMPI_COMM_WORLD_* or cedar_amd_bmg_set_rank); one rank per GPU", nproc, world, rank);
+		report(buf);
+		return nullptr;
 	}
 	auto *t = new topo_t();
 	t->nd = nd;
+	t->rank = rank; t->world = world;
+	// rank = (k * nprocy + j) * nprocx + i (src/2d/interface/c/topo.cc:35-36, src/3d/interface/c/topo.cc)
+	int r = rank;
+	t->uniform = true;
 	for (int d = 0; d < 3; d++) {
+		const int npd = d < nd ? np[d] : 1;
+		t->nproc[d] = npd;
+		t->coord[d] = r % npd;
+		r /= npd;
 		t->ng[d] = d < nd ? ng[d] : 1;
-		t->nl[d] = d < nd ? ln[d][0] : 1; // coord = 0: the first entry of the per-process extent list
+		t->nl[d] = d < nd ? ln[d][t->coord[d]] : 1;
 		t->is[d] = 1;
-		t->nproc[d] = 1;
-		t->coord[d] = 0;
+		for (int i = 0; d < nd && i < t->coord[d]; i++) t->is[d] += ln[d][i];
+		for (int i = 0; d < nd && i < npd; i++) t->uniform = t->uniform && ln[d][i] == ln[d][0];
 	}
 	return t;
 }
@@ -138,6 +203,16 @@ void apply(op_t *o, const double *x, double *b)
 	interior_copy(t, g, x, nullptr);
 	o->upload();
 	cedar_amd_memcpy_h2d(o->dx, g.data(), g.size() * sizeof(real_t));
+	if (t.world > 1) { // the ghost layer of x from the neighbouring ranks (the reference's mpi::stencil_op::apply exchanges it too)
+		cedar_amd::dist::RankCtx c;
+		if (!rank_ctx(t, c)) return;
+		if (!o->halo) {
+			o->halo = new cedar_amd::dist::Halo;
+			const int n3[3] = {(int)t.nl[0], (int)t.nl[1], t.nd == 3 ? (int)t.nl[2] : -1};
+			cedar_amd::dist::halo_init(&c, *o->halo, n3);
+		}
+		cedar_amd::dist::halo_exchange(&c, *o->halo, (int)t.nl[0] + 2, (int)t.nl[1] + 2, t.nd == 3 ? (int)t.nl[2] + 2 : 1, o->dx, 1, 0);
+	}
 	cedar_amd_memset(o->db, 0, g.size() * sizeof(real_t));
 	if (t.nd == 2) cedar_amd_matvec2(o->dso, o->dx, o->db, t.nl[0] + 2, t.nl[1] + 2, o->nst);
 	else cedar_amd_matvec3(o->dso, o->dx, o->db, t.nl[0] + 2, t.nl[1] + 2, t.nl[2] + 2, o->nst);
@@ -165,10 +240,31 @@ slv_t *make_solver(op_t *o)
 	s->st.cycle = ms.cycle;
 	o->upload();
 	const topo_t &t = o->topo;
-	s->h = cedar_amd_solver_create(t.nd, t.nl[0], t.nl[1], t.nd == 3 ? t.nl[2] : 1, o->nst, o->dso, 1, &s->st);
-	if (!s->h) {
-		delete s;
-		return nullptr;
+	if (t.world > 1) {
+		// mpi::solver on the rank grid (src/2d/interface/c/solver.cc:10-22): the domain-decomposed drivers, one rank per GPU
+		cedar_amd_comm *comm;
+		const cedar_amd_transport *tp;
+		if (!t.uniform) {
+			report("bmg_solver_create: the domain-decomposed solver takes the same local extents on every rank");
+			delete s;
+			return nullptr;
+		}
+		if (!transport(t.rank, t.world, comm, tp)) {
+			delete s;
+			return nullptr;
+		}
+		if (t.nd == 2) s->d2 = cedar_amd_dist2_create(comm, tp, t.rank, t.world, t.nproc, o->dso, t.nl[0], t.nl[1], o->nst, &s->st, 0);
+		else s->d3 = cedar_amd_dist3_create(comm, tp, t.rank, t.world, t.nproc, o->dso, t.nl[0], t.nl[1], t.nl[2], o->nst, &s->st, 0, 0);
+		if (!s->d2 && !s->d3) {
+			delete s;
+			return nullptr;
+		}
+	} else {
+		s->h = cedar_amd_solver_create(t.nd, t.nl[0], t.nl[1], t.nd == 3 ? t.nl[2] : 1, o->nst, o->dso, 1, &s->st);
+		if (!s->h) {
+			delete s;
+			return nullptr;
+		}
 	}
 	s->xg.assign(o->pts(), 0.0);
 	s->bg.assign(o->pts(), 0.0);
@@ -183,7 +279,16 @@ void run(slv_t *s, double *x, const double *b)
 	const topo_t &t = s->op->topo;
 	interior_copy(t, s->bg, b, nullptr);
 	std::fill(s->xg.begin(), s->xg.end(), 0.0); // sol.set(0.0), src/2d/interface/c/solver.cc:43
-	cedar_amd_solver_solve(s->h, s->bg.data(), s->xg.data(), s->rel.data());
+	if (s->h) cedar_amd_solver_solve(s->h, s->bg.data(), s->xg.data(), s->rel.data());
+	else {
+		op_t *o = s->op;
+		const size_t bytes = s->bg.size() * sizeof(real_t);
+		cedar_amd_memcpy_h2d(o->db, s->bg.data(), bytes);
+		cedar_amd_memset(o->dx, 0, bytes);
+		if (s->d2) cedar_amd_dist2_solve(s->d2, o->db, o->dx, s->rel.data());
+		else cedar_amd_dist3_solve(s->d3, o->db, o->dx, s->rel.data());
+		cedar_amd_memcpy_d2h(s->xg.data(), o->dx, bytes);
+	}
 	interior_copy(t, s->xg, nullptr, x);
 }
 
@@ -222,6 +327,15 @@ void dump(op_t *o)
 } // namespace
 
 extern "C" {
+
+// who this process is (overrides the launcher's environment) and, optionally, how it talks to the other ranks (a transport
+// table in place of the RCCL communicator the interface would bootstrap itself) -- include/cedar_amd.h section 4
+void cedar_amd_bmg_set_rank(int rank, int world) { g_rank = rank; g_world = world; }
+void cedar_amd_bmg_set_transport(const cedar_amd_transport *tp)
+{
+	g_has_tp = tp && tp->exchange;
+	if (g_has_tp) g_tp = *tp;
+}
 
 bmg2_topo bmg2_topo_create(MPI_Comm, unsigned int ngx, unsigned int ngy, unsigned int lnx[], unsigned int lny[],
                            int nprocx, int nprocy)
@@ -307,7 +421,9 @@ void bmg3_solver_run(bmg3_solver s, double *x, const double *b) { run(reinterpre
 static void destroy_solver(slv_t *s)
 {
 	if (!s) return;
-	cedar_amd_solver_destroy(s->h);
+	if (s->h) cedar_amd_solver_destroy(s->h);
+	if (s->d2) cedar_amd_dist2_destroy(s->d2);
+	if (s->d3) cedar_amd_dist3_destroy(s->d3);
 	delete s;
 }
 void bmg2_solver_destroy(bmg2_solver s) { destroy_solver(reinterpret_cast<slv_t *>(s)); }

@@ -17,7 +17,15 @@
 #include "stage.h"
 #include <dlfcn.h>
 #include <cstring>
+#include <cstdint>
+#include <vector>
 #include <rccl/rccl.h>
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <sys/time.h>
+#include <unistd.h>
 
 using namespace cedar_amd;
 
@@ -139,6 +147,152 @@ void cedar_amd_comm_destroy(cedar_amd_comm *c)
 	(void)hipDeviceSynchronize();
 	if (c->c) (void)rccl().CommDestroy(c->c);
 	delete c;
+}
+
+// ---- launcher-side bootstrap in compiled code: rank 0 makes the unique id and serves it over TCP next to MASTER_PORT, the
+// other ranks fetch it (the protocol of cedar_amd/comm.py bootstrap_bytes, so that Python and C ranks of one job can
+// mix: magic + 16-byte job tag (MASTER_PORT, world size, run id) + rank; the answer echoes magic + tag before the payload).
+// Lets a plain C / C++ / Fortran host (Cedar's C interface, bmg_capi.cpp) create the communicator without Python or MPI.
+namespace {
+
+void sha1(const unsigned char *msg, size_t len, unsigned char out[20])
+{
+	uint32_t h0 = 0x67452301, h1 = 0xEFCDAB89, h2 = 0x98BADCFE, h3 = 0x10325476, h4 = 0xC3D2E1F0;
+	const size_t total = ((len + 8) / 64 + 1) * 64;
+	std::vector<unsigned char> m(total, 0);
+	memcpy(m.data(), msg, len);
+	m[len] = 0x80;
+	const uint64_t bits = (uint64_t)len * 8;
+	for (int i = 0; i < 8; i++) m[total - 1 - i] = (unsigned char)(bits >> (8 * i));
+	for (size_t off = 0; off < total; off += 64) {
+		uint32_t w[80];
+		for (int i = 0; i < 16; i++)
+			w[i] = (uint32_t)m[off + 4 * i] << 24 | (uint32_t)m[off + 4 * i + 1] << 16 | (uint32_t)m[off + 4 * i + 2] << 8 | m[off + 4 * i + 3];
+		for (int i = 16; i < 80; i++) { uint32_t v = w[i - 3] ^ w[i - 8] ^ w[i - 14] ^ w[i - 16]; w[i] = v << 1 | v >> 31; }
+		uint32_t a = h0, b = h1, c = h2, d = h3, e = h4;
+		for (int i = 0; i < 80; i++) {
+			uint32_t f, k;
+			if (i < 20) { f = (b & c) | (~b & d); k = 0x5A827999; }
+			else if (i < 40) { f = b ^ c ^ d; k = 0x6ED9EBA1; }
+			else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8F1BBCDC; }
+			else { f = b ^ c ^ d; k = 0xCA62C1D6; }
+			const uint32_t t = (a << 5 | a >> 27) + f + e + k + w[i];
+			e = d; d = c; c = b << 30 | b >> 2; b = a; a = t;
+		}
+		h0 += a; h1 += b; h2 += c; h3 += d; h4 += e;
+	}
+	const uint32_t hs[5] = {h0, h1, h2, h3, h4};
+	for (int i = 0; i < 5; i++)
+		for (int j = 0; j < 4; j++) out[4 * i + j] = (unsigned char)(hs[i] >> (24 - 8 * j));
+}
+
+bool send_all(int fd, const void *buf, size_t n)
+{
+	const char *p = static_cast<const char *>(buf);
+	while (n) {
+		const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+		if (k <= 0) return false;
+		p += k; n -= (size_t)k;
+	}
+	return true;
+}
+
+bool recv_all(int fd, void *buf, size_t n)
+{
+	char *p = static_cast<char *>(buf);
+	while (n) {
+		const ssize_t k = ::recv(fd, p, n, 0);
+		if (k <= 0) return false;
+		p += k; n -= (size_t)k;
+	}
+	return true;
+}
+
+void set_timeout(int fd, int seconds)
+{
+	timeval tv{seconds, 0};
+	setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+	setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+
+} // namespace
+
+int cedar_amd_comm_bootstrap_id(void *id128, int rank, int world)
+{
+	if (world <= 1) return rank == 0 ? cedar_amd_comm_unique_id(id128) : 1;
+	const char *host = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
+	const char *mp = getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "29500";
+	const int base = atoi(mp);
+	const char *rid = getenv("CEDAR_AMD_RUN_ID") ? getenv("CEDAR_AMD_RUN_ID") : (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "");
+	char key[256];
+	const int klen = snprintf(key, sizeof(key), "%s:%d:%s", mp, world, rid);
+	unsigned char dig[20];
+	sha1(reinterpret_cast<const unsigned char *>(key), (size_t)klen, dig);
+	unsigned char magic[28];
+	memcpy(magic, "CEDARAMDUID1", 12);
+	memcpy(magic + 12, dig, 16);
+	sockaddr_in addr{};
+	addr.sin_family = AF_INET;
+	if (inet_pton(AF_INET, host, &addr.sin_addr) != 1) inet_pton(AF_INET, "127.0.0.1", &addr.sin_addr);
+	if (rank == 0) {
+		if (cedar_amd_comm_unique_id(id128)) return 1;
+		int srv = -1;
+		for (int i = 1; i <= 8 && srv < 0; i++) {
+			const int fd = socket(AF_INET, SOCK_STREAM, 0);
+			int one = 1;
+			setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+			addr.sin_port = htons((uint16_t)(base + i));
+			if (bind(fd, reinterpret_cast<sockaddr *>(&addr), sizeof(addr)) == 0 && listen(fd, world) == 0) srv = fd;
+			else close(fd);
+		}
+		if (srv < 0) { char m[] = "cedar_amd_comm_bootstrap: no free port next to MASTER_PORT"; print_error(m); return 1; }
+		set_timeout(srv, 120);
+		std::vector<char> served((size_t)world, 0);
+		int nserved = 0;
+		while (nserved < world - 1) {
+			const int c = accept(srv, nullptr, nullptr);
+			if (c < 0) { close(srv); char m[] = "cedar_amd_comm_bootstrap: timed out waiting for the other ranks"; print_error(m); return 1; }
+			set_timeout(c, 60);
+			unsigned char got[28];
+			uint32_t r = 0;
+			if (recv_all(c, got, 28) && memcmp(got, magic, 28) == 0 && recv_all(c, &r, 4) && r >= 1 && r < (uint32_t)world && !served[r]) {
+				const uint32_t n = CEDAR_AMD_COMM_ID_BYTES;
+				if (send_all(c, magic, 28) && send_all(c, &n, 4) && send_all(c, id128, n)) { served[r] = 1; nserved++; }
+			}
+			close(c); // another job, a foreign client, a duplicate: neither answered nor counted
+		}
+		close(srv);
+		return 0;
+	}
+	for (int attempt = 0; attempt < 1200; attempt++) { // ~120 s
+		for (int i = 1; i <= 8; i++) {
+			const int fd = socket(AF_INET, SOCK_STREAM, 0);
+			addr.sin_port = htons((uint16_t)(base + i));
+			set_timeout(fd, 3);
+			if (connect(fd, reinterpret_cast<sockaddr *>(&addr), sizeof(addr)) == 0) {
+				const uint32_t r = (uint32_t)rank;
+				unsigned char got[28];
+				uint32_t n = 0;
+				if (send_all(fd, magic, 28) && send_all(fd, &r, 4) && recv_all(fd, got, 28) && memcmp(got, magic, 28) == 0
+				    && recv_all(fd, &n, 4) && n == CEDAR_AMD_COMM_ID_BYTES && recv_all(fd, id128, n)) {
+					close(fd);
+					return 0;
+				}
+			}
+			close(fd);
+		}
+		usleep(100000);
+	}
+	char m[] = "cedar_amd_comm_bootstrap: rank 0 did not serve the unique id";
+	print_error(m);
+	return 1;
+}
+
+cedar_amd_comm *cedar_amd_comm_bootstrap(int rank, int world)
+{
+	unsigned char id[CEDAR_AMD_COMM_ID_BYTES];
+	if (cedar_amd_comm_bootstrap_id(id, rank, world)) return nullptr;
+	return cedar_amd_comm_create(id, rank, world);
 }
 
 int cedar_amd_comm_rank(const cedar_amd_comm *c) { return c->rank; }

@@ -8,10 +8,16 @@
  *   src/{2d,3d}/interface/c/{topo,operator,solver}.cc, src/interface/c/timer.cc.
  * A C caller written against the reference links unchanged against libcedar_amd.so.
  *
- * Scope: the reference implements this interface on its MPI solver.  This library is
- * one process per GPU; the interface here serves the single-rank case (nprocx = nprocy
- * [= nprocz] = 1; the communicator is accepted and not dereferenced).  A topology with
- * more than one process reports through print_error() and yields NULL.
+ * Scope: the reference implements this interface on its MPI solver.  This library is one process per GPU: a topology
+ * with nprocx * nprocy [* nprocz] = 1 runs on the device-resident solver, a larger one on the domain-decomposed
+ * drivers (cedar_amd_dist2_* / cedar_amd_dist3_*, include/cedar_amd.h section 4) -- every rank must then own the same
+ * local extents, even on every level that stays distributed.  The communicator argument is accepted and not
+ * dereferenced (the library links no MPI): the rank comes from the launcher's environment (RANK / PMI_RANK /
+ * OMPI_COMM_WORLD_RANK / SLURM_PROCID with the matching size variables) or cedar_amd_bmg_set_rank, the transport is an
+ * RCCL communicator the interface bootstraps over MASTER_ADDR / MASTER_PORT, or a table handed in with
+ * cedar_amd_bmg_set_transport.  A process grid that does not match the launched ranks reports through print_error()
+ * and yields NULL.  As in the reference a rank sets the entries whose STORAGE location lies in its local array, ghost
+ * layer included (coordinates of ghost vertices are taken).
  *
  * Conventions kept from the reference:
  *  - grid coordinates are 0-based global vertex indices; the operator is given vertex

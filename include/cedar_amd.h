@@ -310,6 +310,12 @@ const char *cedar_amd_comm_why_unavailable(void);
 int cedar_amd_comm_unique_id(void *id128);               /* ncclGetUniqueId */
 cedar_amd_comm *cedar_amd_comm_create(const void *id128, int rank, int world);  /* ncclCommInitRank on the current device */
 void cedar_amd_comm_destroy(cedar_amd_comm *c);
+/* the launcher's part in compiled code, for hosts without Python or MPI: rank 0 makes the unique id and serves it over TCP
+ * on MASTER_ADDR next to MASTER_PORT, the other ranks fetch it; the handshake carries a job tag (MASTER_PORT, world size,
+ * CEDAR_AMD_RUN_ID / TORCHELASTIC_RUN_ID), the wire format is that of cedar_amd/comm.py.  _bootstrap = _bootstrap_id +
+ * cedar_amd_comm_create; returns NULL / non-zero on failure (reported through print_error). */
+int cedar_amd_comm_bootstrap_id(void *id128, int rank, int world);
+cedar_amd_comm *cedar_amd_comm_bootstrap(int rank, int world);
 int cedar_amd_comm_rank(const cedar_amd_comm *c);
 int cedar_amd_comm_size(const cedar_amd_comm *c);
 /* one grouped point-to-point exchange: ncclGroupStart; ncclRecv x nrecv; ncclSend x nsend; ncclGroupEnd (counts in doubles) */
@@ -398,6 +404,14 @@ int cedar_amd_dist2_nlevels(const cedar_amd_dist2 *d);
 void cedar_amd_dist2_vcycle(cedar_amd_dist2 *d, real_t *x_dev, real_t *b_dev);
 int cedar_amd_dist2_solve(cedar_amd_dist2 *d, real_t *b_dev, real_t *x_dev, real_t *rel);
 float cedar_amd_dist2_time_relax(cedar_amd_dist2 *d, real_t *x_dev, real_t *b_dev, int n);
+
+/* Cedar's C interface (include/cedar/capi.h: bmg2_* / bmg3_*) with nprocx * nprocy [* nprocz] > 1 runs on the two drivers
+ * above, as the reference runs it on its MPI solvers (src/2d/interface/c/solver.cc:10-60).  The MPI_Comm argument is not
+ * dereferenced: the rank comes from the launcher's environment (RANK / PMI_RANK / OMPI_COMM_WORLD_RANK / SLURM_PROCID and
+ * the matching size variables) or from cedar_amd_bmg_set_rank; the transport is an RCCL communicator the interface
+ * bootstraps itself (cedar_amd_comm_bootstrap) unless a table is handed in. */
+void cedar_amd_bmg_set_rank(int rank, int world);
+void cedar_amd_bmg_set_transport(const cedar_amd_transport *tp);   /* NULL: back to RCCL */
 
 #ifdef __cplusplus
 }

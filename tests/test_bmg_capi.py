@@ -97,10 +97,14 @@ def _lib():
     L.bmg2_solver_create.argtypes = [C.POINTER(C.c_void_p)]
     L.bmg3_solver_create.argtypes = [C.POINTER(C.c_void_p)]
     L.bmg_timer_save.argtypes = [C.c_char_p]
+    L.cedar_amd_bmg_set_rank.argtypes = [C.c_int, C.c_int]
+    L.cedar_amd_bmg_set_transport.argtypes = [C.c_void_p]
     return L
 
 
-def test_topology_with_several_processes_is_refused():
+def test_topology_that_does_not_match_the_launched_ranks_is_refused():
+    """a 2 x 1 process grid in a job of ONE rank (no RANK / WORLD_SIZE in the environment): reported and NULL.  With
+    matching ranks the interface runs on the domain-decomposed drivers (tests/test_gpu_bmg_dist.py)."""
     L = _lib()
     one = (C.c_uint * 2)(8, 8)
     assert L.bmg2_topo_create(0, 16, 8, one, one, 2, 1) is None

@@ -89,3 +89,36 @@ def test_two_jobs_on_neighbouring_ports_do_not_cross():
     assert len(got) == 2 * world
     for port, rank, payload in got:
         assert payload == want[port], (port, rank)
+
+
+def _c_client(rank, world, port, q):
+    """a rank that fetches the id through the library's compiled bootstrap (cedar_amd_comm_bootstrap_id)"""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from cedar_amd import capi
+    buf = ctypes.create_string_buffer(128)
+    rc = capi.lib.cedar_amd_comm_bootstrap_id(buf, rank, world)
+    q.put((rank, buf.raw if rc == 0 else None))
+
+
+def test_compiled_bootstrap_speaks_the_python_protocol():
+    """cedar_amd_comm_bootstrap_id (comm.cpp: the launcher's part for hosts without Python, used by Cedar's C interface
+    with more than one rank) against a Python rank 0: same magic, job tag (its own SHA-1) and framing"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_worker, args=(0, world, port, 0.3, q)),
+          ctx.Process(target=_c_client, args=(1, world, port, q)),
+          ctx.Process(target=_worker, args=(2, world, port, 0.0, q))]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(30)
+    assert all(got[r] == bytes(range(128)) for r in range(world)), {r: (v[:4] if v else v) for r, v in got.items()}
