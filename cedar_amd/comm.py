@@ -247,14 +247,28 @@ class SocketComm:
         my_port = srv.getsockname()[1]
         # every rank learns every port through rank 0 (gather + broadcast over the bootstrap channel)
         table = self._exchange_ports(my_port)
-        # lower rank connects to higher rank
+        # lower rank connects to higher rank; the greeting carries the job tag: this listener sits on an ephemeral port that
+        # may lie in the candidate range of some rank-0 bootstrap (its clients then knock here and are turned away)
+        hello = _MAGIC + _job_tag(self.world)
         for p in range(self.rank + 1, self.world):
             s = socket.create_connection((host, table[p]), timeout=60.0)
-            s.sendall(struct.pack("<I", self.rank))
+            s.sendall(hello + struct.pack("<I", self.rank))
             self.peers[p] = s
-        for _ in range(self.rank):
+        srv.settimeout(120.0)
+        while len(self.peers) < self.world - 1:
             conn, _a = srv.accept()
-            (p,) = struct.unpack("<I", _recv_exact(conn, 4))
+            conn.settimeout(10.0)
+            try:
+                if _recv_exact(conn, len(hello)) != hello:
+                    conn.close()
+                    continue
+                (p,) = struct.unpack("<I", _recv_exact(conn, 4))
+            except (ConnectionError, socket.timeout, OSError):
+                conn.close()
+                continue
+            if not 0 <= p < self.rank or p in self.peers:
+                conn.close()
+                continue
             self.peers[p] = conn
         srv.close()
         for s in self.peers.values():
@@ -293,9 +307,14 @@ class SocketComm:
                 if not 1 <= r < self.world or r in table:  # a rank of another job, or the same rank twice
                     conn.close()
                     continue
+                try:
+                    conn.sendall(magic)  # at once: the client learns within seconds that it reached ITS rank 0
+                except OSError:
+                    conn.close()
+                    continue
                 table[r] = p
                 conns.append(conn)
-            blob = magic + struct.pack("<%dI" % self.world, *[table[r] for r in range(self.world)])
+            blob = struct.pack("<%dI" % self.world, *[table[r] for r in range(self.world)])
             for conn in conns:
                 conn.sendall(blob)
                 conn.close()
@@ -306,11 +325,12 @@ class SocketComm:
             for port in _ports():
                 try:
                     with socket.create_connection((host, port), timeout=2.0) as s:
-                        s.settimeout(120.0)
+                        s.settimeout(3.0)  # some other listener on a candidate port (another job, a peer socket): move on
                         magic = _MAGIC + _job_tag(self.world)
                         s.sendall(magic + struct.pack("<II", self.rank, my_port))
                         if _recv_exact(s, len(magic)) != magic:
                             continue  # another job's rank 0
+                        s.settimeout(120.0)  # the table comes once every rank has registered
                         blob = _recv_exact(s, 4 * self.world)
                         return list(struct.unpack("<%dI" % self.world, blob))
                 except (OSError, ConnectionError):

@@ -497,8 +497,8 @@ int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_
 	if (!is_device_ptr(so) || !is_device_ptr(sor)) return 0; // staged host arrays change address from call to call
 	const char *e = getenv("CEDAR_AMD_ILV");
 	const int mode = e ? atoi(e) : 320;
-	if (mode <= 0) return 0;
-	return relax3_prepare(so, sor, (int)ii, (int)jj, (int)kk, mode == 1 ? 0 : mode, current_stream());
+	// mode <= 0: no solve copy (the partial-sum scratch is still registered where the sweep wants it)
+	return relax3_prepare(so, sor, (int)ii, (int)jj, (int)kk, mode <= 0 ? -1 : mode == 1 ? 0 : mode, current_stream());
 }
 
 void cedar_amd_relax3_release(const real_t *so) { relax3_release(so); }

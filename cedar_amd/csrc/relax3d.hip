@@ -85,21 +85,26 @@ void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, in
 // Solve copies registered for operators that live outside a resident solver (the per-rank arrays of the
 // domain-decomposed solver, cedar_amd/dist.py): the per-piece entry points below look the operator pointer up and read
 // the row-interleaved copy when there is one.  The caller re-registers after it changed the operator.
-struct IlvReg { real_t *ilv; int II, JJ, KK; };
+struct IlvReg { real_t *ilv, *T; int II, JJ, KK; }; // T: partial-sum scratch of the sweep (relax3d_psum.hip), one vector
 static std::map<const real_t *, IlvReg> g_ilv;
 
 int relax3_prepare(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, hipStream_t st)
 {
 	relax3_release(so);
-	if (JJ - 2 < min_rows || (II - 2 + 1) / 2 > 512) return 0;
 	size_t fr = 0, tot = 0;
 	const size_t bytes = ilv_doubles(II, JJ, KK) * sizeof(real_t);
-	if (hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + tot / 10 >= fr) return 0;
-	real_t *p = nullptr;
-	CEDAR_HIP_CHECK(hipMalloc((void **)&p, bytes));
-	ilv_build(so, sor + (size_t)II * JJ * KK, p, II, JJ, KK, st);
-	g_ilv[so] = IlvReg{p, II, JJ, KK};
-	return 1;
+	const bool want_ilv = min_rows >= 0 && JJ - 2 >= min_rows && (II - 2 + 1) / 2 <= 512 && hipMemGetInfo(&fr, &tot) == hipSuccess
+	                      && bytes + tot / 10 < fr;
+	const bool want_T = relax3_psum_wanted(II, JJ, KK);
+	if (!want_ilv && !want_T) return 0;
+	IlvReg r{nullptr, nullptr, II, JJ, KK};
+	if (want_ilv) {
+		CEDAR_HIP_CHECK(hipMalloc((void **)&r.ilv, bytes));
+		ilv_build(so, sor + (size_t)II * JJ * KK, r.ilv, II, JJ, KK, st);
+	}
+	if (want_T) CEDAR_HIP_CHECK(hipMalloc((void **)&r.T, (size_t)II * JJ * KK * sizeof(real_t)));
+	g_ilv[so] = r;
+	return (want_ilv ? 1 : 0) | (want_T ? 2 : 0);
 }
 
 void relax3_release(const real_t *so)
@@ -108,16 +113,22 @@ void relax3_release(const real_t *so)
 	if (it == g_ilv.end()) return;
 	CEDAR_HIP_CHECK(hipDeviceSynchronize());
 	(void)hipFree(it->second.ilv);
+	(void)hipFree(it->second.T);
 	g_ilv.erase(it);
+}
+
+static const IlvReg *reg_lookup(const real_t *so, int II, int JJ, int KK)
+{
+	if (g_ilv.empty()) return nullptr;
+	auto it = g_ilv.find(so);
+	if (it != g_ilv.end() && it->second.II == II && it->second.JJ == JJ && it->second.KK == KK) return &it->second;
+	return nullptr;
 }
 
 static Op3 op3_lookup(const real_t *so, const real_t *sor, int II, int JJ, int KK)
 {
-	if (!g_ilv.empty()) {
-		auto it = g_ilv.find(so);
-		if (it != g_ilv.end() && it->second.II == II && it->second.JJ == JJ && it->second.KK == KK)
-			return op3_ilv(it->second.ilv, II, JJ, KK);
-	}
+	const IlvReg *r = reg_lookup(so, II, JJ, KK);
+	if (r && r->ilv) return op3_ilv(r->ilv, II, JJ, KK);
 	return op3_cedar(so, sor, II, JJ, KK);
 }
 
@@ -608,8 +619,28 @@ void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t
 	int pieces[2][2] = { { 0, nrk }, { 0, 0 } };
 	if (part == 1) { pieces[0][0] = klo; pieces[0][1] = nki; }
 	else if (part == 2 && nki > 0) { pieces[0][0] = 0; pieces[0][1] = klo; pieces[1][0] = khi; pieces[1][1] = nrk - khi; }
+	// partial sums (relax3d_psum.hip) where the operator was registered with a scratch vector: a k-parity of planes is the
+	// A or the B phase of the sweep; planes next to a neighbouring rank's ghost plane leave / take none (they wait for the halo
+	// and run as small pieces in the reference order)
+	const IlvReg *reg = reg_lookup(so, II, JJ, KK);
+	const int pfrun = relax3_psum_frun(JJ);
+	const bool psum = reg && reg->T && npairs <= 256 && relax3_psum_wanted(II, JJ, KK);
+	const int nbr = ((sides & 4) ? 1 : 0) | ((sides & 8) ? 2 : 0);
+	const bool first_parity = up ? kb == 0 : kb == 1;
 	for (auto &pc : pieces) {
 		if (pc[1] <= 0) continue;
+		if (psum) {
+			const int nrun = ((JJ - 2 - (up ? 0 : 1) + 1) / 2 + pfrun - 1) / pfrun;
+			bool gives = false; // does any plane of an A piece leave partial sums?  (a piece of shell planes does not)
+			for (int kr = pc[0]; kr < pc[0] + pc[1] && !gives; kr++) {
+				const int k = 1 + kb + 2 * kr;
+				gives = !(k == 1 && (nbr & 1)) && !(k == KK - 2 && (nbr & 2));
+			}
+			if (!first_parity || gives || (size_t)pc[1] * (size_t)nrun >= 256) {
+				relax3_planes27_psum(A, qf, q, reg->T, II, JJ, KK, kb, up, pc[0], pc[1], nbr, pfrun, st);
+				continue;
+			}
+		}
 		if (npairs <= 64) planes_bs<64>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);
 		else if (npairs <= 128) planes_bs<128>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);
 		else if (npairs <= 256) planes_bs<256>(up, A, qf, q, II, JJ, KK, kb, pc[0], pc[1], st);

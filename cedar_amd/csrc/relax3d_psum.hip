@@ -30,6 +30,7 @@
 #include "common.h"
 #include "relax27_dev.h"
 #include "relax3_psum.h"
+#include <vector>
 
 namespace cedar_amd {
 
@@ -65,6 +66,19 @@ __host__ __device__ static inline bool psum_row_ok(const PsumGeom &g, int JJ, in
 	int lo, hi;
 	psum_run_range(g, JJ, f / g.frun, lo, hi);
 	return lo + 1 <= j && j <= hi - 1;
+}
+
+// Which planes take part.  nbr: bit 0 / 1 = a neighbouring RANK owns the plane below / above this box (slab
+// decomposition; 0 on a single GPU).  An A plane next to such a ghost plane waits for the halo and runs as a small piece
+// of its own (row kernels): it leaves no partial sums, and the B plane beside it keeps the reference order, like the B
+// planes next to any ghost plane (their other neighbour plane is not an A plane of this box).
+__host__ __device__ static inline bool psum_a_gives(int k, int KK, int nbr)
+{
+	return k >= 1 && k <= KK - 2 && !(k == 1 && (nbr & 1)) && !(k == KK - 2 && (nbr & 2));
+}
+__host__ __device__ static inline bool psum_b_takes(int kp, int KK, int nbr)
+{
+	return kp - 1 >= 1 && kp + 1 <= KK - 2 && psum_a_gives(kp - 1, KK, nbr) && psum_a_gives(kp + 1, KK, nbr);
 }
 
 // X's coefficient towards the point (DI, DJ) of the plane above (SIDE 0) / below (SIDE 1): see offdiag27
@@ -248,8 +262,8 @@ __device__ __forceinline__ void relax27_row_task_A(const Op3 &A, const real_t *_
 // A launch: the plane-fused walk of relax27_plane over the planes of the first k-parity, with the partial sums
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_planeA(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
-                                                      real_t *__restrict__ T, int II, int JJ, int KK, int kb, int nrk,
-                                                      PsumGeom gm)
+                                                      real_t *__restrict__ T, int II, int JJ, int KK, int kb, int kr0,
+                                                      int nrk, int nbr, PsumGeom gm)
 {
 	__shared__ PsumLds<BS> S;
 	const unsigned nblk = (unsigned)nrk * (unsigned)gm.nrun;
@@ -261,10 +275,9 @@ __global__ __launch_bounds__(BS) void relax27_planeA(const Op3 A, const real_t *
 	int lo, hi;
 	psum_run_range(gm, JJ, run, lo, hi);
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
-	const int ki = 1 + kb + 2 * kr;
+	const int ki = 1 + kb + 2 * (kr + kr0);
 	const size_t k = (size_t)ki;
-	// the B plane above (k+1) takes partial sums iff it is interior and so is k+2; likewise below
-	const bool stU = ki + 2 <= KK - 2, stD = ki - 2 >= 1;
+	const bool stU = psum_b_takes(ki + 1, KK, nbr), stD = psum_b_takes(ki - 1, KK, nbr);
 	int t = 0;
 	for (int f = f0; f < f1; f++) {
 		relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(1 + jbF + 2 * f), k, S, t, true, lo, hi, stU, stD);
@@ -431,29 +444,29 @@ __global__ __launch_bounds__(BS) void relax27_planeB(const Op3 A, const real_t *
 
 // Rows of the B planes that keep the reference order, in one launch per row class.
 //   cls 0 (before relax27_planeB): F rows; cls 1 (after it): S rows.
-//   Workgroups [0, ninel*nrows): every row of the class in the planes next to a ghost plane (ninel of them: kr = 0 if
-//   krlo > 0, kr = nrk-1 if krhi < nrk); then per plane kr in [krlo, krhi) ncand candidates: cls 0: the first and the
-//   last F row of every run; cls 1: the S row after every run but the last, row 1 (jbF = 1), the S row beyond the last F.
+//   Workgroups [0, nx*nrows): every row of the class in the nx <= 2 planes x0, x1 that take no partial sums at all; then per
+//   partial-sum plane kr in [elo, ehi) ncand candidates: cls 0: the first and the last F row of every run; cls 1: the S row
+//   after every run but the last, row 1 (jbF = 1), the S row beyond the last F.
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_rows_sel(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
-                                                        int II, int JJ, int KK, int kb, int nrk, int krlo, int krhi,
+                                                        int II, int JJ, int KK, int kb, int elo, int ehi, int x0, int x1,
                                                         PsumGeom gm, int cls)
 {
 	__shared__ real_t xch[BS + 2];
 	const int nrows = cls ? gm.nS : gm.nF;
-	const int ninel = (krlo > 0 ? 1 : 0) + (krhi < nrk ? 1 : 0);
+	const int nx = (x0 >= 0 ? 1 : 0) + (x1 >= 0 ? 1 : 0);
 	int w = (int)blockIdx.x;
 	int kr, j;
-	if (w < ninel * nrows) {
+	if (w < nx * nrows) {
 		const int tpl = w / nrows, r = w % nrows;
-		kr = (tpl == 0 && krlo > 0) ? 0 : nrk - 1;
+		kr = (tpl == 0 && x0 >= 0) ? x0 : x1;
 		j = (cls ? 2 - gm.jbF : 1 + gm.jbF) + 2 * r;
 	} else {
-		w -= ninel * nrows;
+		w -= nx * nrows;
 		const int ncand = cls ? gm.nrun + 1 : 2 * gm.nrun;
-		kr = krlo + w / ncand;
+		kr = elo + w / ncand;
 		const int c = w % ncand;
-		if (kr >= krhi) return;
+		if (kr >= ehi) return;
 		if (cls == 0) {
 			const int run = c >> 1, end = c & 1;
 			const int f0 = run * gm.frun, f1 = min(gm.nF, f0 + gm.frun);
@@ -481,13 +494,64 @@ __global__ __launch_bounds__(BS) void relax27_rows_sel(const Op3 A, const real_t
 // rows j = j0 + jstep*jr of all planes of parity kb, reference order (the S rows between the runs of the A launch)
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_rows_between(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
-                                                            int II, int JJ, int KK, int j0, int jstep, int nrj, int kb, int nrk)
+                                                            int II, int JJ, int KK, int j0, int jstep, int nrj, int kb, int kr0,
+                                                            int nrk)
 {
 	__shared__ real_t xch[BS + 2];
 	const int w = (int)blockIdx.x;
 	if (w >= nrj * nrk) return;
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
-	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, (size_t)(j0 + jstep * (w % nrj)), (size_t)(1 + kb + 2 * (w / nrj)), xch);
+	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, (size_t)(j0 + jstep * (w % nrj)), (size_t)(1 + kb + 2 * (kr0 + w / nrj)), xch);
+}
+
+// A phase on the planes kr0 .. kr0+nrk-1 of the first k-parity kb: the plane-fused walk with partial sums, then the S rows
+// between runs (reference order)
+template <int BS, bool EFIRST>
+static void phase_a(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int kb, int kr0, int nrk,
+                    int nbr, const PsumGeom &gm, hipStream_t st)
+{
+	if (nrk <= 0) return;
+	hipLaunchKernelGGL((relax27_planeA<BS, EFIRST, true>), dim3(xcd_grid((unsigned)nrk * (unsigned)gm.nrun)), dim3(BS), 0, st,
+	                   A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm);
+	if (gm.nrun > 1)
+		hipLaunchKernelGGL((relax27_rows_between<BS, EFIRST, true>), dim3((unsigned)((gm.nrun - 1) * nrk)), dim3(BS), 0, st,
+		                   A, qf, q, II, JJ, KK, (gm.jbF ? 1 : 0) + 2 * gm.frun, 2 * gm.frun, gm.nrun - 1, kb, kr0, nrk);
+}
+
+// B phase on the planes kr0 .. kr0+nrk-1 of the second k-parity kb: the planes that take partial sums form a contiguous
+// range; at most one plane at either end of the piece keeps the reference order altogether
+template <int BS, bool EFIRST>
+static void phase_b(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int kb, int kr0, int nrk,
+                    int nbr, const PsumGeom &gm, hipStream_t st)
+{
+	if (nrk <= 0) return;
+	int elo = kr0, ehi = kr0 + nrk, x0 = -1, x1 = -1;
+	while (elo < ehi && !psum_b_takes(1 + kb + 2 * elo, KK, nbr)) elo++;
+	while (ehi > elo && !psum_b_takes(1 + kb + 2 * (ehi - 1), KK, nbr)) ehi--;
+	// planes of the piece outside [elo, ehi): in a piece of the sweep there is at most one at either end; more (a piece
+	// made of planes next to ghost planes only) go through the reference-order rows two at a time
+	std::vector<int> exact;
+	for (int kr = kr0; kr < kr0 + nrk; kr++)
+		if (kr < elo || kr >= ehi) exact.push_back(kr);
+	const int nel = ehi - elo;
+	size_t done = 0;
+	do {
+		x0 = done < exact.size() ? exact[done] : -1;
+		x1 = done + 1 < exact.size() ? exact[done + 1] : -1;
+		const bool first = done == 0;
+		done += 2;
+		const int nxp = (x0 >= 0 ? 1 : 0) + (x1 >= 0 ? 1 : 0);
+		for (int cls = 0; cls < 2; cls++) {
+			if (cls == 1 && first && nel > 0)
+				hipLaunchKernelGGL((relax27_planeB<BS, EFIRST, true>), dim3(xcd_grid((unsigned)nel * (unsigned)gm.nrun)), dim3(BS), 0, st,
+				                   A, qf, q, T, II, JJ, KK, kb, elo, nel, gm);
+			const int nrows = cls ? gm.nS : gm.nF, ncand = cls ? gm.nrun + 1 : 2 * gm.nrun;
+			const int nwg = nxp * nrows + (first ? nel * ncand : 0);
+			if (nwg > 0)
+				hipLaunchKernelGGL((relax27_rows_sel<BS, EFIRST, true>), dim3((unsigned)nwg), dim3(BS), 0, st,
+				                   A, qf, q, II, JJ, KK, kb, first ? elo : 0, first ? ehi : 0, x0, x1, gm, cls);
+		}
+	} while (done < exact.size());
 }
 
 template <int BS, bool EFIRST>
@@ -496,30 +560,32 @@ static void sweep_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int
 	const bool up = EFIRST; // UP: even i, j-parity 0 rows, k-parity 0 planes first; DOWN the reverse
 	const int jbF = up ? 0 : 1, kbA = up ? 0 : 1, kbB = 1 - kbA;
 	const PsumGeom gm = psum_geom(JJ, jbF, frun);
-	const int nrkA = (KK - 2 - kbA + 1) / 2, nrkB = (KK - 2 - kbB + 1) / 2;
-	if (nrkA > 0) {
-		hipLaunchKernelGGL((relax27_planeA<BS, EFIRST, true>), dim3(xcd_grid((unsigned)nrkA * (unsigned)gm.nrun)), dim3(BS), 0, st,
-		                   A, qf, q, T, II, JJ, KK, kbA, nrkA, gm);
-		if (gm.nrun > 1)
-			hipLaunchKernelGGL((relax27_rows_between<BS, EFIRST, true>), dim3((unsigned)((gm.nrun - 1) * nrkA)), dim3(BS), 0, st,
-			                   A, qf, q, II, JJ, KK, (jbF ? 1 : 0) + 2 * frun, 2 * frun, gm.nrun - 1, kbA, nrkA);
-	}
-	if (nrkB <= 0) return;
-	// B planes k' = 1+kbB+2 kr; next to a ghost plane: k' = 1 (kr = 0, kbB = 0) and k' = KK-2 (the last one, if it has parity kbB)
-	const int krlo = kbB == 0 ? 1 : 0;
-	int krhi = (1 + kbB + 2 * (nrkB - 1) == KK - 2) ? nrkB - 1 : nrkB;
-	if (krhi < krlo) krhi = krlo;
-	const int ninel = (krlo > 0 ? 1 : 0) + (krhi < nrkB ? 1 : 0), nel = krhi - krlo;
-	for (int cls = 0; cls < 2; cls++) {
-		if (cls == 1 && nel > 0)
-			hipLaunchKernelGGL((relax27_planeB<BS, EFIRST, true>), dim3(xcd_grid((unsigned)nel * (unsigned)gm.nrun)), dim3(BS), 0, st,
-			                   A, qf, q, T, II, JJ, KK, kbB, krlo, nel, gm);
-		const int nrows = cls ? gm.nS : gm.nF, ncand = cls ? gm.nrun + 1 : 2 * gm.nrun;
-		const int nwg = ninel * nrows + nel * ncand;
-		if (nwg > 0)
-			hipLaunchKernelGGL((relax27_rows_sel<BS, EFIRST, true>), dim3((unsigned)nwg), dim3(BS), 0, st,
-			                   A, qf, q, II, JJ, KK, kbB, nrkB, krlo, krhi, gm, cls);
-	}
+	phase_a<BS, EFIRST>(A, qf, q, T, II, JJ, KK, kbA, 0, (KK - 2 - kbA + 1) / 2, 0, gm, st);
+	phase_b<BS, EFIRST>(A, qf, q, T, II, JJ, KK, kbB, 0, (KK - 2 - kbB + 1) / 2, 0, gm, st);
+}
+
+// One k-parity of planes of a sweep, the unit between two halo exchanges of a slab decomposition (relax3_planes27): the
+// planes kr0 .. kr0+nrk-1 of parity kb; nbr: which ghost planes belong to a neighbouring rank.
+void relax3_planes27_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int kb, int up, int kr0,
+                          int nrk, int nbr, int frun, hipStream_t st)
+{
+	const int npairs = (II - 2 + 1) / 2;
+	const PsumGeom gm = psum_geom(JJ, up ? 0 : 1, frun);
+	const bool first_parity = up ? kb == 0 : kb == 1;
+#define PSUM_PH(B)                                                                                                  \
+	do {                                                                                                            \
+		if (first_parity) {                                                                                         \
+			if (up) phase_a<B, true>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                           \
+			else phase_a<B, false>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                             \
+		} else {                                                                                                    \
+			if (up) phase_b<B, true>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                           \
+			else phase_b<B, false>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                             \
+		}                                                                                                           \
+	} while (0)
+	if (npairs <= 64) PSUM_PH(64);
+	else if (npairs <= 128) PSUM_PH(128);
+	else PSUM_PH(256);
+#undef PSUM_PH
 }
 
 // the level can take the partial-sum sweep: rows of at most 512 points (LDS of relax27_planeA), runs of frun F rows

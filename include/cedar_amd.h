@@ -165,8 +165,10 @@ void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len
                              int kb, int up, int part);
 /* Register the 27-point operator `so` (device pointer, with its SETUP_recip output `sor`) with the library: on levels
  * with at least 320 rows the pieces above and BMG3_SymStd_relax_GS / _residual then read a row-interleaved solve copy
- *  instead of the fourteen Cedar-layout planes.  Returns 1 if a copy was made.  Call again after
- * the operator changed; release before freeing it.  The resident solver (section 2) does this by itself. */
+ *  instead of the fourteen Cedar-layout planes, and cedar_amd_relax3_planes runs the sweep with
+ * inter-plane partial sums (cedar_amd_relax3_gs_psum below; levels with at least 160 rows, CEDAR_AMD_PSUM=0: never) on a
+ * scratch vector kept with the registration.  Returns bit 0: a solve copy was made, bit 1: the scratch was.  Call again
+ * after the operator changed; release before freeing it.  The resident solver (section 2) does this by itself. */
 int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk);
 void cedar_amd_relax3_release(const real_t *so);
 /* One 27-point sweep (BMG3_SymStd_relax_GS.f90:80-138, Dirichlet) with INTER-PLANE PARTIAL SUMS: the planes of the
