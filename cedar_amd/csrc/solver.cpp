@@ -444,12 +444,19 @@ void fmg_cycle(cedar_amd_solver *s, int lvl, real_t *x, const real_t *b, hipStre
 		return;
 	}
 	Level &L = s->lv[lvl], &K = s->lv[lvl + 1];
-	if (s->nd == 2) restrict2(b, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	// periodic: the kernels of the V-cycle; the periodic restriction refreshes the ghosts of the vector it restricts
+	// (restrict.f90:78-103) -- here the right-hand side itself, which the reference's binding reaches through a const_cast
+	const int ibc = s->st.ibc;
+	if (s->nd == 2 && ibc) restrict2_per(const_cast<real_t *>(b), K.b, K.P, L.II, L.JJ, K.II, K.JJ, ibc, st);
+	else if (s->nd == 2) restrict2(b, K.b, K.P, L.II, L.JJ, K.II, K.JJ, st);
+	else if (ibc) restrict3_per(const_cast<real_t *>(b), K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, ibc, st);
 	else restrict3(b, K.b, K.P, L.II, L.JJ, L.KK, K.II, K.JJ, K.KK, st);
 	fmg_cycle(s, lvl + 1, K.x, K.b, st);
 	zero_fill(x, L.npts, st);
 	zero_fill(L.res, L.npts, st);
-	if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	if (s->nd == 2 && ibc) interp_add2_per(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, ibc, st);
+	else if (s->nd == 2) interp_add2(x, K.x, L.res, L.A, K.P, K.II, K.JJ, L.II, L.JJ, st);
+	else if (ibc) interp_add3_per(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, ibc, st);
 	else interp_add3(x, K.x, L.A, L.res, K.P, K.II, K.JJ, K.KK, L.II, L.JJ, L.KK, st);
 	ncycle(s, lvl, x, b, st);
 }
@@ -597,14 +604,14 @@ static cedar_amd_solver *solver_create(int nd, len_t nx, len_t ny, len_t nz, int
 		CEDAR_HIP_CHECK(hipEventCreateWithFlags(&s->pfork, hipEventDisableTiming));
 	}
 	if (s->st.ibc != 0) {
-		// periodic boundary conditions: V-cycle.  2D: ibc 1..3, point relaxation keeps a row in the default LDS
+		// periodic boundary conditions (V- and F-cycles).  2D: ibc 1..3, point relaxation keeps a row in the default LDS
 		// window; 3D: ibc 1..3, 5..8 (BMG_get_bc.f90:13-20), even extents in the periodic directions on every level
 		// that is coarsened (checked below, once the level sizes are known)
-		const bool ok2 = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3 && s->st.cycle == 0
+		const bool ok2 = nd == 2 && s->st.ibc >= 1 && s->st.ibc <= 3
 		                 && (s->st.relaxation != CEDAR_AMD_RELAX_POINT || (size_t)(nx + 2) * sizeof(real_t) <= 64 * 1024);
-		const bool ok3 = nd == 3 && s->st.ibc > 0 && periodic3_code_ok(s->st.ibc) && s->st.cycle == 0;
+		const bool ok3 = nd == 3 && s->st.ibc > 0 && periodic3_code_ok(s->st.ibc);
 		if (!ok2 && !ok3) {
-			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for V-cycles "
+			char msg[] = "cedar_amd_solver_create: periodic boundary conditions are implemented for the definite periodic codes "
 			             "(2D: ibc 1..3, point relaxation: rows up to 8190 points; 3D: ibc 1..3, 5..8); no solver created";
 			print_error(msg);
 			delete s;

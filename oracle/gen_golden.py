@@ -169,18 +169,19 @@ class RefML:
     def _fmg(self, l, x, b):
         """include/cedar/cycle/fcycle.h:49-83"""
         R = self.R
+        kw = dict(ibc=self.ibc) if self.ibc else {}
         if l == self.nlev - 1:
-            (R.solve_cg2 if self.nd == 2 else R.solve_cg3)(x, b, self.abd)
+            (R.solve_cg2 if self.nd == 2 else R.solve_cg3)(x, b, self.abd, **kw)
             return
         cx, cb, Pm = self.x[l + 1], self.b[l + 1], self.P[l + 1]
-        (R.restrict2 if self.nd == 2 else R.restrict3)(b, cb, Pm)
+        (R.restrict2 if self.nd == 2 else R.restrict3)(b, cb, Pm, **kw)
         self._fmg(l + 1, cx, cb)
         x[...] = 0.0
         self.res[l][...] = 0.0
         if self.nd == 2:
-            R.interp_add2(x, cx, self.res[l], self.A[l], Pm)
+            R.interp_add2(x, cx, self.res[l], self.A[l], Pm, **kw)
         else:
-            R.interp_add3(x, cx, self.A[l], self.res[l], Pm)
+            R.interp_add3(x, cx, self.A[l], self.res[l], Pm, **kw)
         self._cycle(l, x, b)
 
     def vcycle(self, x, b):

@@ -301,12 +301,18 @@ static void fmg_cycle(orc_ml *ml, int lvl, real_t *x, const real_t *b)
 		return;
 	}
 	orc_level *L = &ml->lv[lvl], *K = &ml->lv[lvl + 1];
-	if (ml->nd == 2) orc2_restrict(b, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
+	/* periodic: the same kernels as the V-cycle; the periodic restriction refreshes the ghosts of the vector it restricts
+	 * (restrict.f90:78-103), here the right-hand side itself, as the reference's binding does through its const_cast */
+	if (ml->nd == 2 && ml->ibc) orc2_restrict_per((real_t *)b, K->b, K->P, L->II, L->JJ, K->II, K->JJ, ml->ibc);
+	else if (ml->nd == 2) orc2_restrict(b, K->b, K->P, L->II, L->JJ, K->II, K->JJ);
+	else if (ml->ibc) orc3_restrict_per((real_t *)b, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK, ml->ibc);
 	else orc3_restrict(b, K->b, K->P, L->II, L->JJ, L->KK, K->II, K->JJ, K->KK);
 	fmg_cycle(ml, lvl + 1, K->x, K->b);
 	memset(x, 0, L->npts * sizeof(real_t));
 	memset(L->res, 0, L->npts * sizeof(real_t));
-	if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
+	if (ml->nd == 2 && ml->ibc) orc2_interp_add_per(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ, ml->ibc);
+	else if (ml->nd == 2) orc2_interp_add(x, K->x, L->res, L->A, K->P, K->II, K->JJ, L->II, L->JJ);
+	else if (ml->ibc) orc3_interp_add_per(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK, ml->ibc);
 	else orc3_interp_add(x, K->x, L->A, L->res, K->P, K->II, K->JJ, K->KK, L->II, L->JJ, L->KK);
 	ncycle(ml, lvl, x, b);
 }

@@ -299,6 +299,13 @@ SOLVES_PER = {
     "perrand9_x_100x75_linexy": (lambda: pb.periodic_random_op(100, 75, 5, (True, False), 6),
                                  lambda: pb.periodic_rhs2(100, 75, (True, False)),
                                  dict(relax="line-xy", nrelax_pre=2, nrelax_post=1, ibc=2)),
+    # periodic F-cycles (round 3): include/cedar/cycle/fcycle.h:49-83 with the periodic kernels
+    "perrand9_xy_96x80_f21": (lambda: pb.periodic_random_op(96, 80, 5, (True, True), 5),
+                              lambda: pb.periodic_rhs2(96, 80, (True, True)),
+                              dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=3, cycle="f")),
+    "perpoisson5_x_200x60_linex_f21": (lambda: pb.periodic_poisson2(200, 60, (True, False)),
+                                       lambda: pb.periodic_rhs2(200, 60, (True, False)),
+                                       dict(relax="line-x", nrelax_pre=2, nrelax_post=1, ibc=2, cycle="f")),
 }
 
 
@@ -387,4 +394,7 @@ SOLVES_PER3 = {
     "perrand27_xz_32x20x24_v21": _per3((32, 20, 24), (1, 0, 1), "random", 13) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=6),),
     "perrand27_yz_20x32x32_v11": _per3((20, 32, 32), (0, 1, 1), "random", 14) + (dict(relax="point", nrelax_pre=1, nrelax_post=1, ibc=7),),
     "perrand27_xyz_32_v21": _per3((32, 32, 32), (1, 1, 1), "random", 15) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=8),),
+    # periodic F-cycles (round 3); golden for per_z, the other code against the oracle
+    "perrand27_z_20x24x32_f21": _per3((20, 24, 32), (0, 0, 1), "random", 11) + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=5, cycle="f"),),
+    "perpoisson7_xy_32x32x24_f21": _per3((32, 32, 24), (1, 1, 0), "poisson") + (dict(relax="point", nrelax_pre=2, nrelax_post=1, ibc=3, cycle="f"),),
 }

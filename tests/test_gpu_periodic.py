@@ -61,7 +61,7 @@ def test_periodic_solve_history_vs_reference_golden(name, oracle):
     gold = json.load(open(os.path.join(HERE, "golden", "solves_periodic.json")))[name]
     mk_op, mk_rhs, st = cases.SOLVES_PER[name]
     so, b = mk_op(), mk_rhs()
-    s = capi.Solver(so, relax=st["relax"], nrelax_pre=st["nrelax_pre"], nrelax_post=st["nrelax_post"], ibc=st["ibc"])
+    s = capi.Solver(so, **st)
     assert s.nlevels() == gold["nlevels"]
     x = np.zeros_like(b)
     h = s.solve(b, x)
@@ -84,8 +84,8 @@ def test_periodic_solve_history_vs_reference_golden(name, oracle):
 def test_periodic_solver_refuses_what_it_does_not_serve(capfd):
     from cedar_amd import capi
     with pytest.raises(RuntimeError):
-        capi.Solver(pb.periodic_poisson2(32, 32, (True, False)), cycle="f", ibc=2)
-    assert "periodic boundary conditions are implemented for V-cycles" in capfd.readouterr().err
+        capi.Solver(pb.periodic_poisson2(32, 32, (True, False)), ibc=4)  # 4 is no boundary code (BMG_get_bc.f90:13-20)
+    assert "periodic boundary conditions are implemented for the definite periodic codes" in capfd.readouterr().err
 
 
 def test_periodic_long_lines(K, oracle):
