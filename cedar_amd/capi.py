@@ -163,6 +163,12 @@ class Kernels:
         nst, JJ, II = so.shape
         lib.BMG2_SymStd_relax_GS(1, _p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), 1, int(nst == 3), nst, 2, 1, updown, ibc)
 
+    def relax2_psum(self, so, qf, q, sor, updown):
+        """nine-point sweep with inter-row partial sums (cedar_amd_relax2_gs_psum); returns 1 if that path ran"""
+        nst, JJ, II = so.shape
+        assert nst == 5
+        return lib.cedar_amd_relax2_gs_psum(_p(so), _p(qf), _p(q), _p(sor), u(II), u(JJ), updown)
+
     def setup_lines2(self, so, sor, d, ibc=0):
         nst, JJ, II = so.shape
         f = lib.BMG2_SymStd_SETUP_lines_x if d == "x" else lib.BMG2_SymStd_SETUP_lines_y

@@ -503,6 +503,15 @@ int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_
 
 void cedar_amd_relax3_release(const real_t *so) { relax3_release(so); }
 
+int cedar_amd_relax2_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int updown)
+{
+	const size_t P = (size_t)ii * jj;
+	Staged sso(so, P * 5, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	const int took = relax2_psum_wanted((int)ii, (int)jj) ? 1 : 0;
+	relax2_gs9_psum(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, updown, current_stream());
+	return took;
+}
+
 int cedar_amd_relax3_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, real_t *scratch, len_t ii, len_t jj, len_t kk,
                              int updown)
 {

@@ -9,6 +9,7 @@
 // (64 algorithmic B/DOF), any row length.
 // Bit-identical to the reference CPU build (term order kept, no contraction).
 #include "common.h"
+#include "relax3_psum.h"
 
 namespace cedar_amd {
 
@@ -194,6 +195,202 @@ __global__ __launch_bounds__(BS) void relax9_band(const real_t *__restrict__ so,
 	}
 }
 
+// ------------------------------------------------------------------ band-fused sweep with inter-row partial sums
+// The 2D analogue of relax3d_psum.hip, with the partial sums kept in LDS.  north_star's contract (histories within 1e-10),
+// not bit for bit: BMG2_SymStd_relax_GS stays on the reference order (relax2_gs).
+// An S row reads, besides its own row, the three operator rows (ks, ksw, knw) that couple it to the F row below and the
+// three that couple it to the F row above -- rows the two F tasks of the same workgroup have just streamed for their own
+// updates -- plus the two fresh F rows.  Here each F task multiplies its fresh values with those coefficients while it
+// holds them in registers and adds the products into an LDS row T of the S row above / below (position-wise: own column,
+// then the column to the right, then to the left, a barrier between the three so that every T entry has one writer at a
+// time and a fixed order of additions); the S task between two F rows of the run then computes
+//     q = (qf + w q(i-1) + w_e q(i+1) + T) / diag
+// from ONE operator row (kw), 1/diag, qf and its own row: 5 row streams instead of 14.  S rows whose two F neighbours do
+// not both belong to the run (rows between runs: second small launch; row 1 / the row beyond the last F row: in place) keep
+// the reference order.  LDS: two T rows of II doubles (the S row being filled and the one being consumed).
+template <int BS, bool EFIRST>
+__device__ __forceinline__ void relax9_row_task_F(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                  real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                  int II, size_t sj, size_t PS, size_t row, real_t *xch, real_t *carry_s,
+                                                  real_t *Tup, real_t *Tdn)
+{
+	const int npairs = (II - 2 + 1) / 2;
+	const int nchunks = (npairs + BS - 1) / BS;
+	const int t = threadIdx.x;
+	if (Tup) { // this F row is the first contributor of the S row above: start its sums from zero
+		for (int i = t; i < II; i += BS) Tup[i] = 0.0;
+		__syncthreads();
+	}
+	for (int cc = 0; cc < nchunks; cc++) {
+		const int c = EFIRST ? nchunks - 1 - cc : cc;
+		const int p = c * BS + t;
+		const int ie = 2 * p + 1, io = ie + 1;
+		const bool e_ok = ie <= II - 2, o_ok = io <= II - 2, two = io + 1 <= II - 1;
+		C9 ce, co;
+		real_t qe[3][3], qo[3][3], qfe = 0, qfo = 0, sre = 0, sro = 0, e_new = 0, o_new = 0;
+		if (e_ok) {
+			load_pair9(so, qf, q, row, sj, PS, ie, io, two, ce, co, qe, qo, qfe, qfo);
+			ldpair2(sor + PS + row + ie, true, sre, sro);
+		}
+		const real_t ghostL = qe[1][0], ghostR = o_ok ? qo[1][2] : qe[1][2]; // old values of the ghost columns (p = 0 / last lane)
+		const real_t carry = *carry_s;
+		if (EFIRST) {
+			if (e_ok) { e_new = offdiag9(qfe, ce, qe) * sre; xch[t] = e_new; }
+			__syncthreads();
+			if (o_ok) {
+				qo[1][0] = e_new;
+				if (io + 1 <= II - 2) qo[1][2] = (t < BS - 1) ? xch[t + 1] : carry;
+				o_new = offdiag9(qfo, co, qo) * sro;
+			}
+			if (t == 0) *carry_s = e_new;
+		} else {
+			if (o_ok) { o_new = offdiag9(qfo, co, qo) * sro; xch[t + 1] = o_new; }
+			__syncthreads();
+			if (e_ok) {
+				if (p > 0) qe[1][0] = (t > 0) ? xch[t] : carry;
+				if (o_ok) qe[1][2] = o_new;
+				e_new = offdiag9(qfe, ce, qe) * sre;
+			}
+			if (t == BS - 1) *carry_s = o_new;
+		}
+		if (e_ok) {
+			if (o_ok) {
+				d2u v; v.x = e_new; v.y = o_new;
+				*reinterpret_cast<d2u *>(q + row + ie) = v;
+			} else
+				q[row + ie] = e_new;
+		}
+		// ---- contributions of this chunk's sources to the S rows above (Tup) and below (Tdn).  Sources: e, o (fresh); the
+		// right ghost column as `o` when the row ends on e (old value, only its contribution to the left counts); the left
+		// ghost column with lane p = 0, the right one with the lane of the last interior point when that is an o.
+		const real_t so_v = o_ok ? o_new : ghostR;
+		const bool o_src = o_ok || (e_ok && io == II - 1);
+		if (e_ok) { // own column
+			if (Tup) { Tup[ie] += e_new * ce.s_n; if (o_ok) Tup[io] += o_new * co.s_n; }
+			if (Tdn) { Tdn[ie] += e_new * ce.s; if (o_ok) Tdn[io] += o_new * co.s; }
+		}
+		__syncthreads();
+		if (e_ok) { // the column to the right of each source (targets io and io+1; lane 0 also: ghost column 0 -> column 1)
+			if (Tup) {
+				if (o_ok) Tup[io] += e_new * ce.sw_ne;
+				if (o_ok && io + 1 <= II - 2) Tup[io + 1] += o_new * co.sw_ne;
+				if (p == 0) Tup[1] += ghostL * so[KSW * PS + row + sj + 1];
+			}
+			if (Tdn) {
+				if (o_ok) Tdn[io] += e_new * ce.nw_e;
+				if (o_ok && io + 1 <= II - 2) Tdn[io + 1] += o_new * co.nw_e;
+				if (p == 0) Tdn[1] += ghostL * so[KNW * PS + row + 1];
+			}
+		}
+		__syncthreads();
+		if (e_ok) { // the column to the left of each source (targets ie-1 and ie; the last lane also: ghost column II-1 -> II-2)
+			if (Tup) {
+				if (ie - 1 >= 1) Tup[ie - 1] += e_new * ce.nw_n;
+				if (o_src) Tup[ie] += so_v * co.nw_n;
+				if (o_ok && io == II - 2) Tup[io] += ghostR * so[KNW * PS + row + sj + (size_t)(II - 1)];
+			}
+			if (Tdn) {
+				if (ie - 1 >= 1) Tdn[ie - 1] += e_new * ce.sw;
+				if (o_src) Tdn[ie] += so_v * co.sw;
+				if (o_ok && io == II - 2) Tdn[io] += ghostR * so[KSW * PS + row + (size_t)(II - 1)];
+			}
+		}
+		__syncthreads(); // stores, carry and sums visible before the next chunk
+	}
+}
+
+// S row from its partial sums: term order qf, w, w_e (relax_GS.f90:98-99), then T
+template <int BS, bool EFIRST>
+__device__ __forceinline__ void relax9_row_task_S(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                  real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                  int II, size_t PS, size_t row, real_t *xch, real_t *carry_s, const real_t *T)
+{
+	const int npairs = (II - 2 + 1) / 2;
+	const int nchunks = (npairs + BS - 1) / BS;
+	const int t = threadIdx.x;
+	for (int cc = 0; cc < nchunks; cc++) {
+		const int c = EFIRST ? nchunks - 1 - cc : cc;
+		const int p = c * BS + t;
+		const int ie = 2 * p + 1, io = ie + 1;
+		const bool e_ok = ie <= II - 2, o_ok = io <= II - 2, two = io + 1 <= II - 1;
+		real_t we = 0, wo = 0, wee = 0, weo = 0, qfe = 0, qfo = 0, sre = 0, sro = 0, e_new = 0, o_new = 0;
+		real_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, te = 0, to = 0;
+		if (e_ok) {
+			ldpair2(so + KW * PS + row + ie, true, we, wo);
+			wee = wo;
+			weo = two ? so[KW * PS + row + io + 1] : 0.0;
+			ldpair2(qf + row + ie, true, qfe, qfo);
+			ldpair2(sor + PS + row + ie, true, sre, sro);
+			ldpair2(q + row + ie - 1, true, w0, w1);
+			ldpair2(q + row + io, two, w2, w3);
+			te = T[ie];
+			to = o_ok ? T[io] : 0.0;
+		}
+		const real_t carry = *carry_s;
+		if (EFIRST) {
+			if (e_ok) { e_new = (((qfe + we * w0) + wee * w2) + te) * sre; xch[t] = e_new; }
+			__syncthreads();
+			if (o_ok) {
+				real_t east = w3;
+				if (io + 1 <= II - 2) east = (t < BS - 1) ? xch[t + 1] : carry;
+				o_new = (((qfo + wo * e_new) + weo * east) + to) * sro;
+			}
+			if (t == 0) *carry_s = e_new;
+		} else {
+			if (o_ok) { o_new = (((qfo + wo * w1) + weo * w3) + to) * sro; xch[t + 1] = o_new; }
+			__syncthreads();
+			if (e_ok) {
+				real_t west = w0;
+				if (p > 0) west = (t > 0) ? xch[t] : carry;
+				e_new = (((qfe + we * west) + wee * (o_ok ? o_new : w2)) + te) * sre;
+			}
+			if (t == BS - 1) *carry_s = o_new;
+		}
+		if (e_ok) {
+			if (o_ok) {
+				d2u v; v.x = e_new; v.y = o_new;
+				*reinterpret_cast<d2u *>(q + row + ie) = v;
+			} else
+				q[row + ie] = e_new;
+		}
+		__syncthreads();
+	}
+}
+
+template <int BS, bool EFIRST>
+__global__ __launch_bounds__(BS) void relax9_band_psum(const real_t *__restrict__ so, const real_t *__restrict__ qf,
+                                                        real_t *__restrict__ q, const real_t *__restrict__ sor,
+                                                        int II, int JJ, int jbF, int frun, int nrun, size_t bstride)
+{
+	extern __shared__ real_t lds_band[];
+	const int IIp = (II + 1) & ~1;
+	real_t *T0 = lds_band, *T1 = lds_band + IIp, *xch = lds_band + 2 * IIp, *carry_s = xch + BS + 2;
+	const unsigned run = xcd_remap(blockIdx.x, (unsigned)nrun);
+	if (run >= (unsigned)nrun) return;
+	qf += bstride * blockIdx.y; q += bstride * blockIdx.y; // batch item (common.h Batch)
+	const size_t sj = II, PS = (size_t)II * JJ;
+	const int nF = (JJ - 2 - jbF + 1) / 2, nS = (JJ - 2 - (1 - jbF) + 1) / 2;
+	const int f0 = (int)run * frun, f1 = min(nF, f0 + frun);
+	for (int f = f0; f < f1; f++) {
+		// F(f) starts the sums of the S row between F(f) and F(f+1) (slot f & 1) and completes those of the S row between
+		// F(f-1) and F(f) (slot (f-1) & 1), when that neighbour belongs to the run
+		real_t *Tup = f + 1 <= f1 - 1 ? ((f & 1) ? T1 : T0) : nullptr;
+		real_t *Tdn = f - 1 >= f0 ? (((f - 1) & 1) ? T1 : T0) : nullptr;
+		relax9_row_task_F<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(1 + jbF + 2 * f) * sj, xch, carry_s, Tup, Tdn);
+		const int g = jbF ? f : f - 1;
+		const bool have = jbF ? (f > f0 || f == 0) : (f > f0);
+		if (have && g >= 0 && g < nS) {
+			const size_t rowS = (size_t)(2 - jbF + 2 * g) * sj;
+			if (f > f0) relax9_row_task_S<BS, EFIRST>(so, qf, q, sor, II, PS, rowS, xch, carry_s, ((f - 1) & 1) ? T1 : T0);
+			else relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, rowS, xch, carry_s); // row 1 below the first F row (jbF = 1)
+		}
+	}
+	if (f1 == nF && f1 > f0) { // the S row beyond the last F row (its other neighbour is the ghost row): reference order
+		const int g = jbF ? nF : nF - 1;
+		if (g < nS) relax9_row_task<BS, EFIRST>(so, qf, q, sor, II, sj, PS, (size_t)(2 - jbF + 2 * g) * sj, xch, carry_s);
+	}
+}
+
 // 9-point residual, pair per lane, 16-byte loads (BMG2_SymStd_residual.f90:88-99)
 __global__ __launch_bounds__(256) void residual9_rows(const real_t *__restrict__ so, const real_t *__restrict__ qf,
                                                        const real_t *__restrict__ q, real_t *__restrict__ res,
@@ -306,6 +503,56 @@ static void relax2_sweep9(const real_t *so, const real_t *qf, real_t *q, const r
 	if (down) hipLaunchKernelGGL((relax9_band<256, true>), grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun, bt.stride);
 	else hipLaunchKernelGGL((relax9_band<256, false>), grid, dim3(256), 0, st, so, qf, q, sor, II, JJ, jbF, frun, nrun, bt.stride);
 	// S rows between runs: jbF = 0: j = 2 frun (r+1); jbF = 1: j = 1 + 2 frun (r+1), r = 0 .. nrun-2
+	launch_rows9<256>(down, so, qf, q, sor, II, JJ, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, st, bt);
+}
+
+// The sweep with inter-row partial sums (relax9_band_psum): rows of at most 4098 doubles (two T rows of LDS beside a second
+// workgroup), at least 8 runs.  CEDAR_AMD_FRUN2 gives the run length as for the band-fused sweep.
+static int band_psum_frun(int II, int JJ)
+{
+	const char *e = getenv("CEDAR_AMD_FRUN2");
+	const int ny = JJ - 2;
+	if ((II - 2 + 1) / 2 <= 64 || (size_t)II * 2 * sizeof(real_t) > 68 * 1024) return 0;
+	if (e) {
+		const int frun = atoi(e);
+		return (frun < 2 || ny < 8 * frun) ? 0 : frun;
+	}
+	// measured (profiles/r03_psum2d_run_length.log): 4096^2 0.310 -> 0.299 / 0.260 / 0.320 ms per sweep for runs of 2 / 4 / 8 rows
+	// (a 2D grid has only ny/2 F rows: runs of 8 leave half the compute units idle), 2048^2 and 1024^2 slower than the two
+	// row-class launches at every run length => the finest level of config 2 only
+	return (ny >= 4096 && II - 2 >= 2048) ? 4 : 0;
+}
+
+bool relax2_psum_wanted(int II, int JJ)
+{
+	const char *e = getenv("CEDAR_AMD_PSUM");
+	if (e && atoi(e) == 0) return false;
+	return band_psum_frun(II, JJ) > 0;
+}
+
+void relax2_gs9_psum(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int updown, hipStream_t st,
+                     Batch bt)
+{
+	const bool down = updown == BMG_DOWN;
+	const int frun = band_psum_frun(II, JJ);
+	if (frun == 0) {
+		relax2_sweep9(so, qf, q, sor, II, JJ, down, st, bt);
+		return;
+	}
+	const int jbF = down ? 0 : 1;
+	const int nF = (JJ - 2 - jbF + 1) / 2, nrun = (nF + frun - 1) / frun;
+	const size_t shm = ((size_t)((II + 1) & ~1) * 2 + 256 + 2 + 2) * sizeof(real_t);
+	static bool attr_dev[64] = {false};
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	if (!attr_dev[dev_ & 63]) {
+		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)relax9_band_psum<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+		CEDAR_HIP_CHECK(hipFuncSetAttribute((const void *)relax9_band_psum<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+		attr_dev[dev_ & 63] = true;
+	}
+	const dim3 grid(xcd_grid((unsigned)nrun), bt.n);
+	if (down) hipLaunchKernelGGL((relax9_band_psum<256, true>), grid, dim3(256), shm, st, so, qf, q, sor, II, JJ, jbF, frun, nrun, bt.stride);
+	else hipLaunchKernelGGL((relax9_band_psum<256, false>), grid, dim3(256), shm, st, so, qf, q, sor, II, JJ, jbF, frun, nrun, bt.stride);
 	launch_rows9<256>(down, so, qf, q, sor, II, JJ, (jbF ? 1 : 0) + 2 * frun, 2 * frun, nrun - 1, st, bt);
 }
 

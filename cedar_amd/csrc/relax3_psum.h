@@ -18,4 +18,9 @@ void relax3_planes27_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, 
 // run length of the partial-sum sweep on a level with JJ-2 rows (0 = the level keeps the reference order), relax3d.hip
 int relax3_psum_frun(int JJ);
 
+// relax2d.hip: nine-point sweep with inter-row partial sums kept in LDS (the 2D analogue; same contract)
+bool relax2_psum_wanted(int II, int JJ);
+void relax2_gs9_psum(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int updown, hipStream_t st,
+                     Batch bt = Batch());
+
 } // namespace cedar_amd

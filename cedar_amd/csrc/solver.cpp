@@ -375,7 +375,11 @@ void smooth(const cedar_amd_solver *s, const Level &L, real_t *x, const real_t *
 		}
 		const Batch bt{s->nb, L.npts};
 		switch (s->st.relaxation) {
-		case CEDAR_AMD_RELAX_POINT: relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, bt); break;
+		case CEDAR_AMD_RELAX_POINT:
+			// nine-point levels of at least 4096 rows: the band-fused sweep with inter-row partial sums (relax2d.hip)
+			if (L.nst == 5 && relax2_psum_wanted(L.II, L.JJ)) relax2_gs9_psum(L.A, b, x, L.SOR0, L.II, L.JJ, updown, st, bt);
+			else relax2_gs(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, bt);
+			break;
 		case CEDAR_AMD_RELAX_LINE_X: relax_lines_x(L.A, b, x, L.SOR0, L.II, L.JJ, L.nst, updown, st, ipn, L.PFx, bt); break;
 		case CEDAR_AMD_RELAX_LINE_Y: lines_y(L, x, b, L.SOR0, updown, ipn, st, bt); break;
 		default:

@@ -182,6 +182,11 @@ void cedar_amd_relax3_release(const real_t *so);
  * reference-order sweep was run instead. */
 int cedar_amd_relax3_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, real_t *scratch, len_t ii, len_t jj, len_t kk,
                              int updown);
+/* The 2D analogue for nine-point operators (BMG2_SymStd_relax_GS.f90:89-114): the band-fused sweep whose S rows take the
+ * six couplings to the two neighbouring F rows as ONE partial-sum row kept in LDS by the workgroup that has just relaxed
+ * those F rows.  Same contract as cedar_amd_relax3_gs_psum; the resident solver runs it on levels with at least 4096 rows
+ * (rows of 2048 to 4350 points; CEDAR_AMD_FRUN2 = run length).  Returns 1, or 0 when the reference-order sweep ran. */
+int cedar_amd_relax2_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int updown);
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb);

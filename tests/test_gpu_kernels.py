@@ -139,6 +139,35 @@ def test_partial_sum_relax_matches_reference_order_to_rounding(K, oracle, monkey
     assert took == (6 if ny >= 4 * frun else 0)
 
 
+@pytest.mark.parametrize("frun", [2, 3, 4])
+@pytest.mark.parametrize("shape", [(300, 48), (131, 33), (1100, 25), (260, 24), (514, 40), (1025, 64), (4096, 33)], ids=str)
+def test_partial_sum_relax9_matches_reference_order_to_rounding(K, oracle, monkeypatch, shape, frun):
+    """cedar_amd_relax2_gs_psum (relax9_band_psum): S rows between two F rows of a run take their six inter-row terms as
+    one LDS partial-sum row; rows of one and of several chunks, odd and even nx / ny (ghost columns as sources, row 1 and
+    the last row in the reference order), non-zero ghosts, both directions, three sweeps in a row: 2e-14 of max|q| per
+    sweep against the oracle (BMG2_SymStd_relax_GS itself stays bit for bit, tested above)"""
+    import problems as pb
+    monkeypatch.setenv("CEDAR_AMD_FRUN2", str(frun))
+    nx, ny = shape
+    g = (ny + 2, nx + 2)
+    so = pb.random_op(g, 5, 81, zero_ghost=False)
+    qf, q0 = pb.uniform(g, 82, -1, 1), pb.uniform(g, 83, -1, 1)
+    sor = np.zeros((2,) + g)
+    oracle.setup_recip2(so, sor)
+    took = 0
+    for ud in (0, 1):
+        want, got = q0.copy(), q0.copy()
+        for sweep in range(3):
+            oracle.relax2(so, qf, want, sor, ud)
+            took += K.relax2_psum(so, qf, got, sor, ud)
+            scale = np.max(np.abs(want))
+            assert np.max(np.abs(got - want)) <= 2e-14 * (sweep + 1) * scale, (shape, frun, ud, sweep, np.max(np.abs(got - want)) / scale)
+        m = np.ones(g, bool)
+        m[1:-1, 1:-1] = False
+        assert np.array_equal(got[m], q0[m])
+    assert took == (6 if (ny >= 8 * frun and nx > 128) else 0)
+
+
 @pytest.mark.parametrize("frun", [1, 2, 3, 0])
 @pytest.mark.parametrize("shape", [(300, 48), (131, 33), (1100, 25), (260, 24)], ids=str)
 def test_band_fused_relax9_matches_two_pass_order(K, oracle, monkeypatch, shape, frun):

@@ -40,6 +40,33 @@ def test_solve_history_vs_reference_golden(capi, golden, name):
     np.testing.assert_allclose(h, want, rtol=1e-10, atol=cases.HIST_ATOL.get(name, 1e-14))
 
 
+@pytest.mark.parametrize("name", ["varcoef9_513_v21", "varcoef9_200x120_v21", "varcoef9_1024_v21", "varcoef9_200x120_f21"], ids=str)
+def test_solve_history_with_partial_sum_relax9_vs_reference_golden(capi, golden, monkeypatch, name):
+    """the resident 2D solver with the nine-point partial-sum sweep (relax9_band_psum; by default on levels with >= 4096
+    rows -- none of the golden cases -- here FORCED onto every level with at least 8 runs of 2 rows): the reference's
+    residual histories to 1e-10 relative.  Absolute floor 5e-14 (x ||r0||) instead of the 1e-14 of the reference-order
+    solver: re-associating six terms of every second row's update perturbs x by ~1e-16 |x| per sweep on EVERY level, and
+    thirty sweeps of that show as 2e-14 ||r0|| on the 1024^2 case (measured) -- rounding noise of the iterate itself,
+    where the reference-order kernels contribute none (they are bit-identical) and only the set-up differs."""
+    monkeypatch.setenv("CEDAR_AMD_FRUN2", "2")
+    monkeypatch.setenv("CEDAR_AMD_PSUM", "1")
+    mk_op, mk_rhs, st = cases.SOLVES[name]
+    gold = golden["solves"][name]
+    so, b = mk_op(), mk_rhs()
+    s = capi.Solver(so, **st)
+    x = np.zeros_like(b)
+    h = s.solve(b, x)
+    s.close()
+    want = [float(gold["res0_l2"])] + [float(v) for v in gold["rel_l2"]]
+    np.testing.assert_allclose(h, want, rtol=1e-10, atol=5e-14)
+    monkeypatch.setenv("CEDAR_AMD_PSUM", "0")
+    s = capi.Solver(so, **st)
+    x2 = np.zeros_like(b)
+    s.solve(b, x2)
+    s.close()
+    assert not np.array_equal(x, x2) and np.max(np.abs(x - x2)) <= 1e-12 * np.max(np.abs(x2))
+
+
 HIER = {
     "fe27_24x20x17_v21": (lambda: pb.fe3(24, 20, 17), lambda: pb.rhs3(24, 20, 17), dict(relax="point")),
     "fe27_40x33x50_v21": (lambda: pb.fe3(40, 33, 50), lambda: pb.rhs3(40, 33, 50), dict(relax="point")),
