@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(HERE, "lib", "libcedar_amd.so")
+LIBPATH = os.environ.get("CEDAR_AMD_LIBPATH") or os.path.join(HERE, "lib", "libcedar_amd.so")  # override: A/B of two builds
 if not os.path.exists(LIBPATH):
     # not built yet (fresh checkout): compile the HIP sources in-tree; still no CPU fallback
     import shutil
