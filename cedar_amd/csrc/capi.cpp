@@ -492,6 +492,34 @@ void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_
 	relax3_fixup27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, icol, jb, kb, current_stream());
 }
 
+void cedar_amd_relax3_rows(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int j0, int jstep,
+                           int nrj, int kb, int efirst)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_rows27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, j0, jstep, nrj, kb, efirst, current_stream());
+}
+
+void cedar_amd_relax3_cols(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int jb, int kb,
+                           int ncol, const int *cols, int xrow0, int xrow1)
+{
+	size_t P = (size_t)ii * jj * kk;
+	Staged sso(so, P * 14, true, false), sqf(qf, P, true, false), sq(q, P, true, true), ssor(sor, P * 2, true, false);
+	relax3_cols27(sso.get(), sqf.get(), sq.get(), ssor.get(), (int)ii, (int)jj, (int)kk, jb, kb, ncol, cols, xrow0, xrow1,
+	              current_stream());
+}
+
+int cedar_amd_relax3_planes_masked(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int kb,
+                                   int up, unsigned cols_f, unsigned cols_s, const int *rows)
+{
+	if (!is_device_ptr(so) || !is_device_ptr(q) || !is_device_ptr(qf) || !is_device_ptr(sor)) return 0; // registered operators only
+	if (((ii - 2) & 1) || ((jj - 2) & 1) || ii - 2 < 8) return 0;
+	PsumSkip sk = psum_skip_none();
+	sk.colsF = cols_f & 0xffu; sk.colsS = cols_s & 0xffu;
+	for (int t = 0; t < 3; t++) sk.rows[t] = rows ? rows[t] : -1;
+	return relax3_planes27_masked(so, qf, q, sor, (int)ii, (int)jj, (int)kk, kb, up, sk, current_stream()) ? 1 : 0;
+}
+
 int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk)
 {
 	if (!is_device_ptr(so) || !is_device_ptr(sor)) return 0; // staged host arrays change address from call to call

@@ -31,6 +31,7 @@ struct DLevel {
 	size_t npts = 0;
 	real_t *A = nullptr, *P = nullptr, *x = nullptr, *b = nullptr, *res = nullptr, *sor = nullptr;
 	bool ownA = true, overlap = false;
+	bool chain = false; // x / y split and the level takes the partial-sum sweep: boundary-first chain + one masked launch per k-parity
 	Halo halo;
 };
 
@@ -80,10 +81,88 @@ void gather_into(cedar_amd_dist3 *d, real_t *local, int lII, int lJJ, int lKK, i
 }
 
 // ---- cycle pieces
+// One k-parity of planes on a rank grid with an x / y split, partial-sum sweep (relax3d_psum.hip).  The plane-fused launch
+// relaxes both row classes and both i-colours of a plane in one go, while the reference's MPI sweep exchanges after every
+// colour (src/3d/ftn/mpi/BMG3_SymStd_relax_GS.f90:102-147).  Boundary-first: the points next to a neighbouring rank, closed
+// under "needs the fresh value of" within the four colours of the parity, are relaxed ahead in the reference order, stage
+// by stage with the exchanges between -- a few columns and rows; the launch then relaxes everything else and leaves those
+// points as they are (every point of the rest that a chain point neighbours comes LATER in the colour order, or the chain
+// would contain it, so the rest sees exactly the values the serial sweep sees).
+//   colours of a parity in sweep order: F rows first colour (c1), F rows c2, S rows c1, S rows c2;
+//   side P of x: its boundary column is c1 (UP: the low side), side Q: c2.   d = distance of a column from the boundary.
+//   chain, side Q: F c1 {d1,d3}, F c2 {d0,d2}, S c1 {d1}, S c2 {d0};   side P: F c1 {d0,d2}, F c2 {d1}, S c1 {d0}
+//   side P of y: its boundary row is an F row (UP: the low side): that row;   side Q: F row d1, S row d0 (whole rows)
+// Both colours of a row class run in one kernel with the ghost column of side Q still stale: its c2 column d0 is
+// recomputed after the exchange (nobody has read it in between) -- four exchanges within the rank's z layer per parity,
+// then the launch, then the exchange across z.
+void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, bool up)
+{
+	const int nx = L.n[0], ny = L.n[1];
+	const int jbF = up ? 0 : 1, jbS = 1 - jbF;
+	int colsF[8], colsS[8], fixc[2], nF = 0, nS = 0, nfix = 0;
+	unsigned mF = 0, mS = 0;
+	int c1[2][2], c2[2][2], n1[2] = {0, 0}, n2[2] = {0, 0}; // per side: columns of the F stage by colour
+	for (int side = 0; side < 2; side++) { // 0 = low x, 1 = high x
+		if (!has_nb(d, 0, side ? +1 : -1)) continue;
+		const bool isP = (side == 0) == up;
+		auto col = [&](int dd) { return side ? nx - dd : 1 + dd; };
+		auto bit = [&](int dd) { return 1u << (side ? 7 - dd : dd); };
+		if (isP) {
+			c1[side][n1[side]++] = col(0); c1[side][n1[side]++] = col(2); c2[side][n2[side]++] = col(1);
+			mF |= bit(0) | bit(1) | bit(2);
+			colsS[nS++] = col(0);
+			mS |= bit(0);
+		} else {
+			c1[side][n1[side]++] = col(1); c1[side][n1[side]++] = col(3); c2[side][n2[side]++] = col(2); c2[side][n2[side]++] = col(0);
+			mF |= bit(0) | bit(1) | bit(2) | bit(3);
+			colsS[nS++] = col(1); colsS[nS++] = col(0); // c1 then c2 (two sides: the low side's c2 before the high side's c1 is harmless, they do not couple)
+			mS |= bit(0) | bit(1);
+			fixc[nfix++] = col(0);
+		}
+	}
+	for (int side = 0; side < 2; side++) for (int t = 0; t < n1[side]; t++) colsF[nF++] = c1[side][t];
+	for (int side = 0; side < 2; side++) for (int t = 0; t < n2[side]; t++) colsF[nF++] = c2[side][t];
+	int rowsF[2], rowS = -1, nrF = 0;
+	for (int side = 0; side < 2; side++) { // 0 = low y, 1 = high y
+		if (!has_nb(d, 1, side ? +1 : -1)) continue;
+		const bool isP = (side == 0) == up;
+		auto row = [&](int dd) { return side ? ny - dd : 1 + dd; };
+		if (isP) rowsF[nrF++] = row(0);
+		else { rowsF[nrF++] = row(1); rowS = row(0); }
+	}
+	const int skip[3] = {nrF > 0 ? rowsF[0] : -1, nrF > 1 ? rowsF[1] : -1, rowS};
+	const bool xs = d->p[0] > 1;
+	// F rows
+	if (nrF) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowsF[0], nrF > 1 ? rowsF[1] - rowsF[0] : 2, nrF, kb, up);
+	if (nF) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbF, kb, nF, colsF, skip[0], skip[1]);
+	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3);
+	if (xs) {
+		if (nfix) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbF, kb, nfix, fixc, -1, -1);
+		halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3);
+	}
+	// S rows
+	if (rowS >= 0) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowS, 2, 1, kb, up);
+	if (nS) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbS, kb, nS, colsS, rowS, -1);
+	if (xs) {
+		halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3);
+		if (nfix) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbS, kb, nfix, fixc, -1, -1);
+	}
+	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3); // ghost columns are sources of the launch's partial sums
+	if (!cedar_amd_relax3_planes_masked(L.A, b, x, L.sor, L.II, L.JJ, L.KK, kb, up, mF, mS, skip)) {
+		char m[] = "cedar_amd_dist3: the masked launch refused a level set up for it";
+		print_error(m);
+	}
+	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 4);
+}
+
 void smooth(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int updown, int nsweeps)
 {
 	const bool up = updown == BMG_UP;
 	for (int it = 0; it < nsweeps; it++) {
+		if (L.chain) {
+			for (int c = 0; c < 2; c++) chain_parity(d, L, x, b, up ? c : 1 - c, up);
+			continue;
+		}
 		if (L.nst == 4) {
 			for (int c = 0; c < 2; c++) {
 				cedar_amd_relax3_colour7(L.A, b, x, L.sor, L.II, L.JJ, L.KK, up ? c : 1 - c);
@@ -198,6 +277,10 @@ void setup(cedar_amd_dist3 *d)
 		// slab decomposition: its sweeps are the plane-fused passes of the single-GPU solver, which read the
 		// row-interleaved solve copy where one is registered (worth 7 %; neutral on rank grids with an x / y split)
 		if (F.nst == 14 && d->p[0] == 1 && d->p[1] == 1) cedar_amd_relax3_prepare(F.A, F.sor, F.II, F.JJ, F.KK);
+		// x / y split: where the level takes the partial-sum sweep (scratch registered: bit 1), the boundary-first chain
+		// (chain_parity); CEDAR_AMD_DIST_CHAIN=0 keeps the reference-order row-class passes
+		else if (F.nst == 14 && F.n[0] >= 8 && F.n[1] >= 8 && !(getenv("CEDAR_AMD_DIST_CHAIN") && !atoi(getenv("CEDAR_AMD_DIST_CHAIN"))))
+			F.chain = (cedar_amd_relax3_prepare(F.A, F.sor, F.II, F.JJ, F.KK) & 2) != 0;
 	}
 	// level la: the global operator on every rank; the single-domain device-resident solver takes over from there
 	DLevel &C = d->lv.back();
@@ -392,6 +475,12 @@ void cedar_amd_dist3_destroy(cedar_amd_dist3 *d)
 
 int cedar_amd_dist3_nlevels(const cedar_amd_dist3 *d) { return d ? d->nlev_global : 0; }
 int cedar_amd_dist3_distributed_levels(const cedar_amd_dist3 *d) { return d ? (int)d->lv.size() : 0; }
+int cedar_amd_dist3_chain_levels(const cedar_amd_dist3 *d)
+{
+	int n = 0;
+	if (d) for (const DLevel &L : d->lv) n += L.chain ? 1 : 0;
+	return n;
+}
 
 void cedar_amd_dist3_vcycle(cedar_amd_dist3 *d, real_t *x, real_t *b)
 {

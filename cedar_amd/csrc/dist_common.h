@@ -29,7 +29,8 @@ struct Halo {
 	int n[3] = {0, 0, 0};
 	std::vector<HaloEntry> nb;
 	size_t total = 0;
-	HaloGroup grp[3]; // 0 = every neighbour, 1 = across an x face / edge / corner, 2 = the others (y/z)
+	HaloGroup grp[5]; // 0 = every neighbour, 1 = across an x face / edge / corner, 2 = the others (y/z),
+	                  // 3 = the neighbours in the rank's own z layer (x / y faces and the four edges between them), 4 = the others
 	std::map<long, std::pair<real_t *, real_t *>> bufs;
 };
 
@@ -122,11 +123,11 @@ static inline void halo_init(RankCtx *d, Halo &h, const int n[3])
 				h.nb.push_back(e);
 			}
 	h.total = off;
-	for (int g = 0; g < 3; g++) {
+	for (int g = 0; g < 5; g++) {
 		HaloGroup &G = h.grp[g];
 		for (size_t i = 0; i < h.nb.size(); i++) {
 			const HaloEntry &e = h.nb[i];
-			if ((g == 1 && e.o[0] == 0) || (g == 2 && e.o[0] != 0)) continue;
+			if ((g == 1 && e.o[0] == 0) || (g == 2 && e.o[0] != 0) || (g == 3 && e.o[2] != 0) || (g == 4 && e.o[2] == 0)) continue;
 			G.idx.push_back((int)i);
 			for (int t = 0; t < 6; t++) { G.sboxes.push_back(e.sbox[t]); G.rboxes.push_back(e.rbox[t]); }
 			G.offs.push_back((unsigned long long)e.off);

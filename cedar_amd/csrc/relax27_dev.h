@@ -158,6 +158,18 @@ __device__ __forceinline__ void load_pair27(const Op3 &A, const real_t *__restri
 		}
 }
 
+// Points a launch leaves as they are (already relaxed by the boundary-first chain of this k-parity, dist3.cpp): `skm`
+// bits 0..3 = the points at offsets 1, 2, 3, 4 of the row (lane 0: e, o; lane 1: e, o), bits 4..7 = the last four interior
+// points (lane P-2: e, o; lane P-1: e, o; P = pairs per row, even extents), bit 8 = the whole row.  A skipped point
+// enters every later use (second colour, partial sums, store) with the value it has.
+__device__ __forceinline__ void skip27_lane(unsigned skm, int p, int P, bool &ske, bool &sko)
+{
+	if (skm & 0x100u) { ske = sko = true; return; }
+	const int slot = p == 0 ? 0 : p == 1 ? 2 : p == P - 2 ? 4 : p == P - 1 ? 6 : -1;
+	ske = slot >= 0 && ((skm >> slot) & 1u);
+	sko = slot >= 0 && ((skm >> (slot + 1)) & 1u);
+}
+
 // one row task: lane p relaxes the pair (ie, io) = (2p+1, 2p+2) of the row at offset `row`, both
 // i-colours, in place.  xch: BS+2 doubles of LDS for the first colour's fresh values.  Every wave of
 // the workgroup must call it (one __syncthreads inside).
@@ -166,10 +178,12 @@ __device__ __forceinline__ void load_pair27(const Op3 &A, const real_t *__restri
 //   PERX: the row is periodic in x with an EVEN number of points: the ghost refresh the reference performs between and
 //   after the two colours (q(1) = q(nx+1), q(nx+2) = q(2), BMG3_SymStd_relax_GS.f90:266-269) happens here -- the last
 //   point of the second colour takes the fresh first point from LDS, and the two ghost cells are written at the end.
-template <int BS, bool EFIRST, bool NT, bool NTP = NT, int WI = 0, bool PERX = false>
+//   MSK / skm: points of the row that were relaxed AHEAD of this launch (boundary-first chain of a rank grid with an
+//   x / y split, dist3.cpp) keep their value -- see skip27_lane.
+template <int BS, bool EFIRST, bool NT, bool NTP = NT, int WI = 0, bool PERX = false, bool MSK = false>
 __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__restrict__ qf,
                                                  real_t *__restrict__ q, int II, size_t sj, size_t sk,
-                                                 size_t j, size_t k, real_t *xch)
+                                                 size_t j, size_t k, real_t *xch, unsigned skm = 0)
 {
 	const size_t row = j * sj + k * sk, rowA = j * A.SJ + k * A.SK;
 	const int p = threadIdx.x;
@@ -189,9 +203,11 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 		ldpair(A.sor + j * A.rSJ + k * A.rSK + ie, true, a_, b_); sre = a_; sro = b_;
 	}
 
+	bool ske = false, sko = false;
+	if (MSK) skip27_lane(skm, p, (II - 2 + 1) / 2, ske, sko);
 	if (EFIRST) {
 		if (e_ok) {
-			e_new = offdiag27(qfe, ce, qe) * sre;
+			e_new = (MSK && ske) ? qe[1][1][1] : offdiag27(qfe, ce, qe) * sre;
 			xch[p] = e_new;
 		}
 		__syncthreads();
@@ -199,7 +215,7 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 			qo[1][1][0] = e_new;
 			if (io + 1 <= II - 2) qo[1][1][2] = xch[p + 1]; // next pair's fresh e (else ghost: old value)
 			else if (PERX) qo[1][1][2] = xch[0];            // periodic: the ghost was refreshed with the row's first point
-			o_new = offdiag27(qfo, co, qo) * sro;
+			o_new = (MSK && sko) ? qo[1][1][1] : offdiag27(qfo, co, qo) * sro;
 		}
 		if (PERX && o_ok && io == II - 2) { // the two ghost cells: left = last point, right = first point
 			q[row] = o_new;
@@ -207,7 +223,7 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 		}
 	} else {
 		if (o_ok) {
-			o_new = offdiag27(qfo, co, qo) * sro;
+			o_new = (MSK && sko) ? qo[1][1][1] : offdiag27(qfo, co, qo) * sro;
 			xch[p + 1] = o_new;
 		}
 		__syncthreads();
@@ -215,7 +231,7 @@ __device__ __forceinline__ void relax27_row_task(const Op3 &A, const real_t *__r
 			if (p > 0) qe[1][1][0] = xch[p]; // previous pair's fresh o (p == 0: ghost column)
 			else if (PERX) qe[1][1][0] = xch[(II - 2) / 2]; // periodic: the ghost was refreshed with the row's last point
 			if (o_ok) qe[1][1][2] = o_new;
-			e_new = offdiag27(qfe, ce, qe) * sre;
+			e_new = (MSK && ske) ? qe[1][1][1] : offdiag27(qfe, ce, qe) * sre;
 		}
 		if (PERX && p == 0 && e_ok) {
 			q[row] = xch[(II - 2) / 2];

@@ -134,7 +134,7 @@ static Op3 op3_lookup(const real_t *so, const real_t *sor, int II, int JJ, int K
 
 // direct-from-memory evaluation at one point (generic path; x = vector offset of (i,j,k), xa = operator offset)
 __device__ __forceinline__ real_t offdiag27_mem(const Op3 &A, const real_t *__restrict__ qf,
-                                                const real_t *__restrict__ q, size_t II, size_t JJ,
+                                                const real_t *q, size_t II, size_t JJ, // (q: relax27_cols reads what it wrote)
                                                 size_t x, size_t xa)
 {
 	const size_t sj = II, sk = II * JJ;
@@ -573,6 +573,55 @@ void relax3_fixup27(const real_t *so, const real_t *qf, real_t *q, const real_t 
 	hipLaunchKernelGGL(relax27_column, dim3((nj * nk + 127) / 128), dim3(128), 0, st, A, qf, q, II, JJ, KK, icol, jb, kb);
 }
 
+// ---- boundary-first chain of a rank grid with an x / y split (dist3.cpp smooth): the few columns and rows next to a
+// neighbouring rank are relaxed stage by stage ahead of the big launch of a k-parity, which then leaves them as they are
+struct ChainCols {
+	int n, col[8], xrow[2];
+};
+
+// one thread per (row of class jb, plane of parity kb): the row's points in the listed columns, in order, through memory
+// (a later point of the list reads the earlier ones' fresh values like any other neighbour)
+__global__ void relax27_cols(const Op3 A, const real_t *__restrict__ qf, real_t *q, int II, int JJ, int KK, int jb, int kb,
+                             ChainCols cc)
+{
+	const int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nj * nk) return;
+	const int jr = 1 + jb + 2 * (t % nj);
+	if (jr == cc.xrow[0] || jr == cc.xrow[1]) return;
+	const size_t j = (size_t)jr, k = (size_t)(1 + kb + 2 * (t / nj));
+	for (int c = 0; c < cc.n; c++) {
+		const size_t i = (size_t)cc.col[c];
+		const size_t x = i + (size_t)II * (j + (size_t)JJ * k);
+		q[x] = offdiag27_mem(A, qf, q, II, JJ, x, i + j * A.SJ + k * A.SK) * A.sor[i + j * A.rSJ + k * A.rSK];
+	}
+}
+
+void relax3_cols27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int KK, int jb, int kb,
+                   int ncol, const int *cols, int xrow0, int xrow1, hipStream_t st)
+{
+	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
+	const int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	if (nj <= 0 || nk <= 0 || ncol <= 0) return;
+	ChainCols cc;
+	cc.n = ncol < 8 ? ncol : 8;
+	for (int c = 0; c < 8; c++) cc.col[c] = c < cc.n ? cols[c] : 1;
+	cc.xrow[0] = xrow0; cc.xrow[1] = xrow1;
+	hipLaunchKernelGGL(relax27_cols, dim3((nj * nk + 63) / 64), dim3(64), 0, st, A, qf, q, II, JJ, KK, jb, kb, cc);
+}
+
+void relax3_rows27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int KK, int j0, int jstep,
+                   int nrj, int kb, int efirst, hipStream_t st)
+{
+	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
+	const int nrk = (KK - 2 - kb + 1) / 2, npairs = (II - 2 + 1) / 2;
+	if (nrj <= 0 || nrk <= 0) return;
+	if (npairs <= 64) launch_rows_at<64>(efirst, A, qf, q, II, JJ, KK, j0, jstep, nrj, kb, nrk, st, 0);
+	else if (npairs <= 128) launch_rows_at<128>(efirst, A, qf, q, II, JJ, KK, j0, jstep, nrj, kb, nrk, st, 0);
+	else if (npairs <= 256) launch_rows_at<256>(efirst, A, qf, q, II, JJ, KK, j0, jstep, nrj, kb, nrk, st, 0);
+	else launch_rows_at<512>(efirst, A, qf, q, II, JJ, KK, j0, jstep, nrj, kb, nrk, st, 0);
+}
+
 void relax3_colour7(const real_t *so, const real_t *qf, real_t *q, const real_t *sor,
                     int II, int JJ, int KK, int pts, hipStream_t st)
 {
@@ -656,6 +705,17 @@ void relax3_planes27(const real_t *so, const real_t *qf, real_t *q, const real_t
 			break;
 		}
 	}
+}
+
+bool relax3_planes27_masked(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int KK, int kb,
+                            int up, const PsumSkip &skip, hipStream_t st)
+{
+	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
+	const IlvReg *reg = reg_lookup(so, II, JJ, KK);
+	const int npairs = (II - 2 + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
+	if (!(reg && reg->T && npairs >= 4 && npairs <= 256 && relax3_psum_wanted(II, JJ, KK))) return false;
+	if (nrk > 0) relax3_planes27_psum(A, qf, q, reg->T, II, JJ, KK, kb, up, 0, nrk, 0, relax3_psum_frun(JJ), st, &skip);
+	return true;
 }
 
 // Run length of the partial-sum sweep (relax3d_psum.hip).  A longer run leaves fewer rows in the reference order (3 in

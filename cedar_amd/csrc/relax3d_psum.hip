@@ -124,7 +124,8 @@ struct PsumLds {
 template <int BS, bool EFIRST, bool NT>
 __device__ __forceinline__ void relax27_row_task_A(const Op3 &A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                                    real_t *__restrict__ T, int II, size_t sj, size_t sk, size_t j, size_t k,
-                                                   PsumLds<BS> &S, int t, bool isf, int lo, int hi, bool stU, bool stD)
+                                                   PsumLds<BS> &S, int t, bool isf, int lo, int hi, bool stU, bool stD,
+                                                   unsigned skm)
 {
 	const size_t row = j * sj + k * sk, rowA = j * A.SJ + k * A.SK;
 	const int p = threadIdx.x;
@@ -148,27 +149,29 @@ __device__ __forceinline__ void relax27_row_task_A(const Op3 &A, const real_t *_
 	const real_t ghostL = qe[1][1][0];                    // lane 0: q(0,j,k)
 	const real_t ghostR = o_ok ? qo[1][1][2] : qe[1][1][2]; // the lane holding the last interior point: q(II-1,j,k)
 
+	bool ske = false, sko = false; // points relaxed ahead of the launch keep their value (relax27_dev.h skip27_lane)
+	if (skm) skip27_lane(skm, p, (II - 2 + 1) / 2, ske, sko);
 	if (EFIRST) {
 		if (e_ok) {
-			e_new = offdiag27(qfe, ce, qe) * sre;
+			e_new = ske ? qe[1][1][1] : offdiag27(qfe, ce, qe) * sre;
 			xch[p] = e_new;
 		}
 		__syncthreads();
 		if (o_ok) {
 			qo[1][1][0] = e_new;
 			if (io + 1 <= II - 2) qo[1][1][2] = xch[p + 1];
-			o_new = offdiag27(qfo, co, qo) * sro;
+			o_new = sko ? qo[1][1][1] : offdiag27(qfo, co, qo) * sro;
 		}
 	} else {
 		if (o_ok) {
-			o_new = offdiag27(qfo, co, qo) * sro;
+			o_new = sko ? qo[1][1][1] : offdiag27(qfo, co, qo) * sro;
 			xch[p + 1] = o_new;
 		}
 		__syncthreads();
 		if (e_ok) {
 			if (p > 0) qe[1][1][0] = xch[p];
 			if (o_ok) qe[1][1][2] = o_new;
-			e_new = offdiag27(qfe, ce, qe) * sre;
+			e_new = ske ? qe[1][1][1] : offdiag27(qfe, ce, qe) * sre;
 		}
 	}
 	if (e_ok) {
@@ -263,7 +266,7 @@ __device__ __forceinline__ void relax27_row_task_A(const Op3 &A, const real_t *_
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_planeA(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                                       real_t *__restrict__ T, int II, int JJ, int KK, int kb, int kr0,
-                                                      int nrk, int nbr, PsumGeom gm)
+                                                      int nrk, int nbr, PsumGeom gm, PsumSkip skp)
 {
 	__shared__ PsumLds<BS> S;
 	const unsigned nblk = (unsigned)nrk * (unsigned)gm.nrun;
@@ -280,13 +283,15 @@ __global__ __launch_bounds__(BS) void relax27_planeA(const Op3 A, const real_t *
 	const bool stU = psum_b_takes(ki + 1, KK, nbr), stD = psum_b_takes(ki - 1, KK, nbr);
 	int t = 0;
 	for (int f = f0; f < f1; f++) {
-		relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(1 + jbF + 2 * f), k, S, t, true, lo, hi, stU, stD);
+		relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(1 + jbF + 2 * f), k, S, t, true, lo, hi, stU, stD,
+		                                   psum_skip_mask(skp, 1 + jbF + 2 * f, true));
 		t++;
 		const int g = jbF ? f : f - 1;
 		const bool have = jbF ? (f > f0 || f == 0) : (f > f0);
 		if (have && g >= 0 && g < nS) {
 			__syncthreads();
-			relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, S, t, false, lo, hi, stU, stD);
+			relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, S, t, false, lo, hi, stU, stD,
+			                                   psum_skip_mask(skp, 2 - jbF + 2 * g, false));
 			t++;
 		}
 	}
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(BS) void relax27_planeA(const Op3 A, const real_t *
 		const int g = jbF ? nF : nF - 1;
 		if (g < nS) {
 			__syncthreads();
-			relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, S, t, false, lo, hi, stU, stD);
+			relax27_row_task_A<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)(2 - jbF + 2 * g), k, S, t, false, lo, hi, stU, stD,
+			                                   psum_skip_mask(skp, 2 - jbF + 2 * g, false));
 			t++;
 		}
 	}
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(BS) void relax27_planeA(const Op3 A, const real_t *
 template <int BS, bool EFIRST, bool NT>
 __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                                    const real_t *__restrict__ T, int II, size_t sj, size_t sk, size_t j,
-                                                   size_t k, real_t *xch)
+                                                   size_t k, real_t *xch, unsigned skm)
 {
 	const size_t row = j * sj + k * sk, rowA = j * A.SJ + k * A.SK;
 	const int p = threadIdx.x;
@@ -346,6 +352,9 @@ __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *_
 #define INPLANE(qf_, pw_, pnwn_, psn_, pswne_, pwe_, pnwe_, ps_, psw_, W, C, E, tb_, tt_) \
 	((((((((((qf_ + pw_ * W(1)) + pnwn_ * W(2)) + psn_ * C(2)) + pswne_ * E(2)) + pwe_ * E(1)) + pnwe_ * E(0)) + ps_ * C(0)) + psw_ * W(0)) + tb_) + tt_)
 	real_t e_new = 0.0, o_new = 0.0;
+	bool ske = false, sko = false;
+	if (skm) skip27_lane(skm, p, (II - 2 + 1) / 2, ske, sko);
+	const real_t e_old = w[1][1], o_old = w[1][2];
 	if (EFIRST) {
 		if (e_ok) {
 #define W_(d) w[d][0]
@@ -355,6 +364,7 @@ __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *_
 #undef W_
 #undef C_
 #undef E_
+			if (ske) e_new = e_old;
 			xch[p] = e_new;
 		}
 		__syncthreads();
@@ -368,6 +378,7 @@ __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *_
 #undef W_
 #undef C_
 #undef E_
+			if (sko) o_new = o_old;
 		}
 	} else {
 		if (o_ok) {
@@ -378,6 +389,7 @@ __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *_
 #undef W_
 #undef C_
 #undef E_
+			if (sko) o_new = o_old;
 			xch[p + 1] = o_new;
 		}
 		__syncthreads();
@@ -391,6 +403,7 @@ __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *_
 #undef W_
 #undef C_
 #undef E_
+			if (ske) e_new = e_old;
 		}
 	}
 #undef INPLANE
@@ -409,7 +422,7 @@ __device__ __forceinline__ void relax27_row_task_B(const Op3 &A, const real_t *_
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_planeB(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                                       const real_t *__restrict__ T, int II, int JJ, int KK, int kb, int kr0,
-                                                      int nrk, PsumGeom gm)
+                                                      int nrk, PsumGeom gm, PsumSkip skp)
 {
 	__shared__ real_t xch[2][BS + 2];
 	const unsigned nblk = (unsigned)nrk * (unsigned)gm.nrun;
@@ -425,17 +438,19 @@ __global__ __launch_bounds__(BS) void relax27_planeB(const Op3 A, const real_t *
 	int t = 0;
 	for (int f = f0; f < f1; f++) {
 		const int jf = 1 + jbF + 2 * f;
-		if (jf >= lo + 1 && jf <= hi - 1) {
+		const unsigned mf = psum_skip_mask(skp, jf, true);
+		if (jf >= lo + 1 && jf <= hi - 1 && !(mf & 0x100u)) {
 			if (t) __syncthreads();
-			relax27_row_task_B<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)jf, k, xch[t & 1]);
+			relax27_row_task_B<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)jf, k, xch[t & 1], mf);
 			t++;
 		}
 		const int g = jbF ? f : f - 1;
 		const bool have = jbF ? (f > f0 || f == 0) : (f > f0);
 		const int js = 2 - jbF + 2 * g;
-		if (have && g >= 0 && g < nS && js >= lo + 1 && js <= hi - 1) {
+		const unsigned ms = psum_skip_mask(skp, js, false);
+		if (have && g >= 0 && g < nS && js >= lo + 1 && js <= hi - 1 && !(ms & 0x100u)) {
 			if (t) __syncthreads();
-			relax27_row_task_B<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)js, k, xch[t & 1]);
+			relax27_row_task_B<BS, EFIRST, NT>(A, qf, q, T, II, sj, sk, (size_t)js, k, xch[t & 1], ms);
 			t++;
 		}
 	}
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(BS) void relax27_planeB(const Op3 A, const real_t *
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_rows_sel(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                                         int II, int JJ, int KK, int kb, int elo, int ehi, int x0, int x1,
-                                                        PsumGeom gm, int cls)
+                                                        PsumGeom gm, int cls, PsumSkip skp)
 {
 	__shared__ real_t xch[BS + 2];
 	const int nrows = cls ? gm.nS : gm.nF;
@@ -488,41 +503,46 @@ __global__ __launch_bounds__(BS) void relax27_rows_sel(const Op3 A, const real_t
 		}
 	}
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
-	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, (size_t)j, (size_t)(1 + kb + 2 * kr), xch);
+	const unsigned m = psum_skip_mask(skp, j, cls == 0);
+	if (m & 0x100u) return;
+	relax27_row_task<BS, EFIRST, NT, NT, 0, false, true>(A, qf, q, II, sj, sk, (size_t)j, (size_t)(1 + kb + 2 * kr), xch, m);
 }
 
 // rows j = j0 + jstep*jr of all planes of parity kb, reference order (the S rows between the runs of the A launch)
 template <int BS, bool EFIRST, bool NT>
 __global__ __launch_bounds__(BS) void relax27_rows_between(const Op3 A, const real_t *__restrict__ qf, real_t *__restrict__ q,
                                                             int II, int JJ, int KK, int j0, int jstep, int nrj, int kb, int kr0,
-                                                            int nrk)
+                                                            int nrk, PsumSkip skp)
 {
 	__shared__ real_t xch[BS + 2];
 	const int w = (int)blockIdx.x;
 	if (w >= nrj * nrk) return;
 	const size_t sj = (size_t)II, sk = (size_t)II * JJ;
-	relax27_row_task<BS, EFIRST, NT>(A, qf, q, II, sj, sk, (size_t)(j0 + jstep * (w % nrj)), (size_t)(1 + kb + 2 * (kr0 + w / nrj)), xch);
+	const int j = j0 + jstep * (w % nrj);
+	const unsigned m = psum_skip_mask(skp, j, false); // S rows of the walk
+	if (m & 0x100u) return;
+	relax27_row_task<BS, EFIRST, NT, NT, 0, false, true>(A, qf, q, II, sj, sk, (size_t)j, (size_t)(1 + kb + 2 * (kr0 + w / nrj)), xch, m);
 }
 
 // A phase on the planes kr0 .. kr0+nrk-1 of the first k-parity kb: the plane-fused walk with partial sums, then the S rows
 // between runs (reference order)
 template <int BS, bool EFIRST>
 static void phase_a(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int kb, int kr0, int nrk,
-                    int nbr, const PsumGeom &gm, hipStream_t st)
+                    int nbr, const PsumGeom &gm, hipStream_t st, const PsumSkip &skp)
 {
 	if (nrk <= 0) return;
 	hipLaunchKernelGGL((relax27_planeA<BS, EFIRST, true>), dim3(xcd_grid((unsigned)nrk * (unsigned)gm.nrun)), dim3(BS), 0, st,
-	                   A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm);
+	                   A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, skp);
 	if (gm.nrun > 1)
 		hipLaunchKernelGGL((relax27_rows_between<BS, EFIRST, true>), dim3((unsigned)((gm.nrun - 1) * nrk)), dim3(BS), 0, st,
-		                   A, qf, q, II, JJ, KK, (gm.jbF ? 1 : 0) + 2 * gm.frun, 2 * gm.frun, gm.nrun - 1, kb, kr0, nrk);
+		                   A, qf, q, II, JJ, KK, (gm.jbF ? 1 : 0) + 2 * gm.frun, 2 * gm.frun, gm.nrun - 1, kb, kr0, nrk, skp);
 }
 
 // B phase on the planes kr0 .. kr0+nrk-1 of the second k-parity kb: the planes that take partial sums form a contiguous
 // range; at most one plane at either end of the piece keeps the reference order altogether
 template <int BS, bool EFIRST>
 static void phase_b(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int kb, int kr0, int nrk,
-                    int nbr, const PsumGeom &gm, hipStream_t st)
+                    int nbr, const PsumGeom &gm, hipStream_t st, const PsumSkip &skp)
 {
 	if (nrk <= 0) return;
 	int elo = kr0, ehi = kr0 + nrk, x0 = -1, x1 = -1;
@@ -544,12 +564,12 @@ static void phase_b(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II
 		for (int cls = 0; cls < 2; cls++) {
 			if (cls == 1 && first && nel > 0)
 				hipLaunchKernelGGL((relax27_planeB<BS, EFIRST, true>), dim3(xcd_grid((unsigned)nel * (unsigned)gm.nrun)), dim3(BS), 0, st,
-				                   A, qf, q, T, II, JJ, KK, kb, elo, nel, gm);
+				                   A, qf, q, T, II, JJ, KK, kb, elo, nel, gm, skp);
 			const int nrows = cls ? gm.nS : gm.nF, ncand = cls ? gm.nrun + 1 : 2 * gm.nrun;
 			const int nwg = nxp * nrows + (first ? nel * ncand : 0);
 			if (nwg > 0)
 				hipLaunchKernelGGL((relax27_rows_sel<BS, EFIRST, true>), dim3((unsigned)nwg), dim3(BS), 0, st,
-				                   A, qf, q, II, JJ, KK, kb, first ? elo : 0, first ? ehi : 0, x0, x1, gm, cls);
+				                   A, qf, q, II, JJ, KK, kb, first ? elo : 0, first ? ehi : 0, x0, x1, gm, cls, skp);
 		}
 	} while (done < exact.size());
 }
@@ -560,26 +580,28 @@ static void sweep_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int
 	const bool up = EFIRST; // UP: even i, j-parity 0 rows, k-parity 0 planes first; DOWN the reverse
 	const int jbF = up ? 0 : 1, kbA = up ? 0 : 1, kbB = 1 - kbA;
 	const PsumGeom gm = psum_geom(JJ, jbF, frun);
-	phase_a<BS, EFIRST>(A, qf, q, T, II, JJ, KK, kbA, 0, (KK - 2 - kbA + 1) / 2, 0, gm, st);
-	phase_b<BS, EFIRST>(A, qf, q, T, II, JJ, KK, kbB, 0, (KK - 2 - kbB + 1) / 2, 0, gm, st);
+	const PsumSkip none = psum_skip_none();
+	phase_a<BS, EFIRST>(A, qf, q, T, II, JJ, KK, kbA, 0, (KK - 2 - kbA + 1) / 2, 0, gm, st, none);
+	phase_b<BS, EFIRST>(A, qf, q, T, II, JJ, KK, kbB, 0, (KK - 2 - kbB + 1) / 2, 0, gm, st, none);
 }
 
 // One k-parity of planes of a sweep, the unit between two halo exchanges of a slab decomposition (relax3_planes27): the
 // planes kr0 .. kr0+nrk-1 of parity kb; nbr: which ghost planes belong to a neighbouring rank.
 void relax3_planes27_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, int II, int JJ, int KK, int kb, int up, int kr0,
-                          int nrk, int nbr, int frun, hipStream_t st)
+                          int nrk, int nbr, int frun, hipStream_t st, const PsumSkip *skip)
 {
 	const int npairs = (II - 2 + 1) / 2;
 	const PsumGeom gm = psum_geom(JJ, up ? 0 : 1, frun);
+	const PsumSkip skp = skip ? *skip : psum_skip_none();
 	const bool first_parity = up ? kb == 0 : kb == 1;
 #define PSUM_PH(B)                                                                                                  \
 	do {                                                                                                            \
 		if (first_parity) {                                                                                         \
-			if (up) phase_a<B, true>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                           \
-			else phase_a<B, false>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                             \
+			if (up) phase_a<B, true>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st, skp);                          \
+			else phase_a<B, false>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st, skp);                            \
 		} else {                                                                                                    \
-			if (up) phase_b<B, true>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                           \
-			else phase_b<B, false>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st);                             \
+			if (up) phase_b<B, true>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st, skp);                          \
+			else phase_b<B, false>(A, qf, q, T, II, JJ, KK, kb, kr0, nrk, nbr, gm, st, skp);                            \
 		}                                                                                                           \
 	} while (0)
 	if (npairs <= 64) PSUM_PH(64);

@@ -35,6 +35,7 @@ lib.cedar_amd_dist3_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
 lib.cedar_amd_dist3_destroy.argtypes = [C.c_void_p]
 lib.cedar_amd_dist3_nlevels.argtypes = [C.c_void_p]
 lib.cedar_amd_dist3_distributed_levels.argtypes = [C.c_void_p]
+lib.cedar_amd_dist3_chain_levels.argtypes = [C.c_void_p]
 lib.cedar_amd_dist3_vcycle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 lib.cedar_amd_dist3_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.cedar_amd_dist3_time_relax.restype = C.c_float
@@ -135,6 +136,7 @@ class DistSolver3:
         if not self.h:
             raise RuntimeError("cedar_amd_dist3_create failed")
         self.nlev_global = lib.cedar_amd_dist3_nlevels(self.h)
+        self.chain_levels = lib.cedar_amd_dist3_chain_levels(self.h)
         self.coord = (rank % self.p[0], (rank // self.p[0]) % self.p[1], rank // (self.p[0] * self.p[1]))
 
     def vcycle(self, x, b):

@@ -190,6 +190,24 @@ int cedar_amd_relax2_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, len
 /* recompute column icol (0-based incl. ghost) of that row class after its x-neighbour column changed */
 void cedar_amd_relax3_fixup(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                             int icol, int jb, int kb);
+/* Boundary-first pieces of a k-parity of planes on a rank grid with an x / y split (what cedar_amd_dist3_* runs where the
+ * level takes the partial-sum sweep; the MPI flavour of the reference exchanges after every colour,
+ * src/3d/ftn/mpi/BMG3_SymStd_relax_GS.f90:102-147).  The few columns and rows whose values a neighbouring rank waits for,
+ * or which wait for a neighbour's, are relaxed stage by stage in the reference order with the exchanges between the
+ * stages; one launch then relaxes everything else of the parity and leaves those points as they are:
+ *   _rows: rows j0, j0+jstep, .. (nrj rows, 0-based incl. ghost) of every plane of parity kb, both i-colours;
+ *   _cols: the points of the listed columns (0-based incl. ghost, relaxed in the order given) in every row of class
+ *          (jb,kb) except the rows xrow0 / xrow1 (-1: none);
+ *   _planes_masked: cedar_amd_relax3_planes for all planes of the parity, with the points named by the masks skipped --
+ *          cols_f / cols_s for the first / second row class of the sweep order: bits 0..3 = columns 1..4, bits 4..7 = the
+ *          last four owned columns; rows[3]: whole rows (-1: unused).  Needs even extents, at least 8 columns and the
+ *          registration of cedar_amd_relax3_prepare with its scratch; returns 0 (nothing done) otherwise. */
+void cedar_amd_relax3_rows(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int j0, int jstep,
+                           int nrj, int kb, int efirst);
+void cedar_amd_relax3_cols(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int jb, int kb,
+                           int ncol, const int *cols, int xrow0, int xrow1);
+int cedar_amd_relax3_planes_masked(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int kb,
+                                   int up, unsigned cols_f, unsigned cols_s, const int *rows);
 /* one colour of the 7-point red-black sweep (pts = 0|1, BMG3_SymStd_relax_GS.f90:155-184) */
 void cedar_amd_relax3_colour7(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                               int pts);
@@ -386,6 +404,9 @@ cedar_amd_dist3 *cedar_amd_dist3_create(cedar_amd_comm *comm, const cedar_amd_tr
 void cedar_amd_dist3_destroy(cedar_amd_dist3 *d);
 int cedar_amd_dist3_nlevels(const cedar_amd_dist3 *d);            /* levels of the global hierarchy */
 int cedar_amd_dist3_distributed_levels(const cedar_amd_dist3 *d); /* of which this many are distributed (the last one gathered) */
+/* distributed levels of a rank grid with an x / y split that relax with the partial-sum sweep behind a boundary-first
+ * chain (cedar_amd_relax3_planes_masked; CEDAR_AMD_DIST_CHAIN=0: none, the reference-order row-class passes everywhere) */
+int cedar_amd_dist3_chain_levels(const cedar_amd_dist3 *d);
 /* one V-cycle on this rank's device-resident x, b (local boxes incl. ghost layer) */
 void cedar_amd_dist3_vcycle(cedar_amd_dist3 *d, real_t *x_dev, real_t *b_dev);
 /* mpi::solver::solve: rel[0] = ||r0||_2, rel[i] = ||r_i||_2 / ||r0||_2 (global norms); returns the cycles run */

@@ -25,13 +25,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, pgrid, outdir, overlap_min, driver="python"):
+def _worker(rank, world, port, n, pgrid, outdir, overlap_min, driver="python", agg=64):
     for p in (HERE, ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("CEDAR_AMD_TEST_STUCK_S", "600")), exit=True)  # a stuck rank says where
     import problems as pb
     from cedar_amd import capi
     from cedar_amd.comm import SocketComm
@@ -55,8 +57,10 @@ def _worker(rank, world, port, n, pgrid, outdir, overlap_min, driver="python"):
         x = be.zeros(b.shape)
         if driver == "native":  # the orchestration below the C ABI (cedar_amd/csrc/dist3.cpp); Python hands over arrays + transport
             from cedar_amd.dist3 import DistSolver3 as Native
-            s = Native(comm, rank, world, A, pgrid=pgrid, max_iter=5, overlap_min=overlap_min)
+            s = Native(comm, rank, world, A, pgrid=pgrid, max_iter=5, overlap_min=overlap_min, agglomerate_below=agg)
             assert s.coord == topo.coord
+            if rank == 0:
+                open(os.path.join(outdir, "chain_levels.txt"), "w").write(str(s.chain_levels))
         else:
             s = DistSolver3(be, topo, A, max_iter=5, overlap_min=overlap_min)
         h = s.solve(b, x)
@@ -123,6 +127,26 @@ def test_native_driver_ranks_sharing_one_gpu_equal_single_domain(n, pgrid, overl
     solution, on every rank grid shape, with and without the overlapped y/z halo, slab and row-class sweeps"""
     world = pgrid[0] * pgrid[1] * pgrid[2]
     _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), overlap_min, "native"))
+    _check_against_single_domain(n, pgrid, tmp_path, oracle)
+
+
+# Rank grids with an x / y split where the levels take the partial-sum sweep (runs of 2 rows so that boxes of a few thousand
+# points qualify): boundary-first chain + one masked launch per k-parity (dist3.cpp chain_parity).  Every role of a rank:
+# neighbour on the low / high / both sides in x and in y, with and without a z split.
+CHAIN_CASES = [((16, 32, 8), (2, 2, 1)), ((16, 16, 8), (3, 1, 1)), ((8, 24, 8), (1, 3, 1)), ((16, 16, 8), (2, 1, 2)),
+               ((8, 16, 8), (1, 2, 2)), ((32, 32, 16), (2, 2, 1))]
+CHAIN_IDS = ["4ranks-xy", "3ranks-x", "3ranks-y", "4ranks-xz", "4ranks-yz", "4ranks-xy-two-chain-levels"]
+
+
+@pytest.mark.parametrize("n,pgrid", CHAIN_CASES, ids=CHAIN_IDS)
+def test_native_driver_boundary_first_chain_equals_single_domain(n, pgrid, tmp_path, oracle, monkeypatch):
+    """the partial-sum sweep on rank grids with an x / y split: columns and rows next to a neighbouring rank relaxed ahead,
+    stage by stage, the rest of a k-parity in one masked launch -- the single-domain history and solution"""
+    monkeypatch.setenv("CEDAR_AMD_FRUN", "2")
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    two = n[0] >= 32  # levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered), both on the chain
+    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), 96, "native", 4 if two else 64))
+    assert int(open(tmp_path / "chain_levels.txt").read()) == (2 if two else 1)
     _check_against_single_domain(n, pgrid, tmp_path, oracle)
 
 

@@ -64,7 +64,10 @@ def run(f, k):
     return (t1 - t0) / k * 1e3, (t2 - t0) / k * 1e3
 
 
-host, total = run(lambda: ds.vcycle(x, b), 5)
+only = os.environ.get("DIST_OVERHEAD_ONLY", "")  # "native": just the native driver (for a profiler run)
+if only == "native":
+    ds.vcycle(x, b)
+host, total = (0.0, 0.0) if only == "native" else run(lambda: ds.vcycle(x, b), 5)
 print(json.dumps({"n": n, "solver": "DistSolver3, one rank of %dx%dx%d%s" % (pg + (" (self-talking mock)" if world > 1 else "",)),
                   "levels_distributed": len(ds.levels), "overlap_min": overlap_min, "host_ms_per_vcycle": host, "ms_per_vcycle": total}), flush=True)
 # the same rank of the same grid on the native driver (cedar_amd_dist3_*, orchestration below the C ABI)
@@ -77,6 +80,8 @@ host, total = run(lambda: dn.vcycle(xn, b), 5)
 print(json.dumps({"n": n, "solver": "cedar_amd_dist3 (native driver), one rank of %dx%dx%d%s" % (pg + (" (loop-back transport)" if world > 1 else "",)),
                   "overlap_min": overlap_min, "host_ms_per_vcycle": host, "ms_per_vcycle": total}), flush=True)
 dn.close()
+if only == "native":
+    sys.exit(0)
 s = capi.Solver(A, share_operator=True)
 xs = be.zeros(g)
 host, total = run(lambda: capi.lib.cedar_amd_solver_vcycle(s.h, xs.ptr, b.ptr), 5)
