@@ -583,6 +583,12 @@ void cedar_amd_box_copy(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, 
 	box_copy(arr, (int)ii, (int)jj, (int)kk, nplanes, nboxes, boxes, offsets, buf, unpack, current_stream());
 }
 
+void cedar_amd_box_copy_strided(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, int nboxes,
+                                const int *boxes, const unsigned long long *offsets, real_t *buf, int unpack)
+{
+	box_copy(arr, (int)ii, (int)jj, (int)kk, nplanes, nboxes, boxes, offsets, buf, unpack, current_stream(), 1);
+}
+
 // ------------------------------------------------------------------ 3D drop-ins
 void BMG3_SymStd_SETUP_recip(real_t *so, real_t *sor, len_t nx, len_t ny, len_t nz, int nstencl, int nsorv)
 {

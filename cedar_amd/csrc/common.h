@@ -178,7 +178,7 @@ void interp_add2(real_t *q, const real_t *qc, real_t *res, const real_t *so, con
 void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, const real_t *ci,
                  int IIC, int JJC, int KKC, int IIF, int JJF, int KKF, hipStream_t st);
 void box_copy(real_t *arr, int II, int JJ, int KK, int nplanes, int nboxes, const int *boxes,
-              const unsigned long long *offsets, real_t *buf, int unpack, hipStream_t st);
+              const unsigned long long *offsets, real_t *buf, int unpack, hipStream_t st, int strided = 0);
 // setup_interp.hip
 void setup_interp2(const real_t *so, real_t *ci, int IIF, int JJF, int IIC, int JJC, int ifd, hipStream_t st);
 void setup_interp3(const real_t *so, real_t *ci, int IIF, int JJF, int KKF,

@@ -132,27 +132,36 @@ void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, b
 	}
 	const int skip[3] = {nrF > 0 ? rowsF[0] : -1, nrF > 1 ? rowsF[1] : -1, rowS};
 	const bool xs = d->p[0] > 1;
+	// what a stage has changed: rows of one class in the planes of the parity; side Q's fixed column travels one way only
+	const int jparF = (1 + jbF) & 1, jparS = (1 + jbS) & 1, kpar = (1 + kb) & 1, qdir = up ? +1 : -1;
+	auto layer = [](const int *o) { return o[2] == 0; };
+	auto across = [](const int *o) { return o[2] != 0; };
+	auto to_q = [&](const int *o) { return o[2] == 0 && o[0] == qdir; };
+	auto to_p = [&](const int *o) { return o[2] == 0 && o[0] == -qdir; };
+	// the fixed column also sits in the boundary row a y neighbour has already received: everything but the messages across side P
+	auto not_p = [&](const int *o) { return o[2] == 0 && o[0] != -qdir; };
+	auto not_q = [&](const int *o) { return o[2] == 0 && o[0] != qdir; };
 	// F rows
 	if (nrF) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowsF[0], nrF > 1 ? rowsF[1] - rowsF[0] : 2, nrF, kb, up);
 	if (nF) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbF, kb, nF, colsF, skip[0], skip[1]);
-	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3);
+	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, jparF, kpar);
 	if (xs) {
 		if (nfix) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbF, kb, nfix, fixc, -1, -1);
-		halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3);
+		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, not_p, not_q, jparF, kpar);
 	}
 	// S rows
 	if (rowS >= 0) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowS, 2, 1, kb, up);
 	if (nS) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbS, kb, nS, colsS, rowS, -1);
 	if (xs) {
-		halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3);
+		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, to_p, to_q, jparS, kpar); // side P's first colour to the neighbour's side Q
 		if (nfix) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbS, kb, nfix, fixc, -1, -1);
 	}
-	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 3); // ghost columns are sources of the launch's partial sums
+	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, jparS, kpar); // ghost columns are sources of the launch's partial sums
 	if (!cedar_amd_relax3_planes_masked(L.A, b, x, L.sor, L.II, L.JJ, L.KK, kb, up, mF, mS, skip)) {
 		char m[] = "cedar_amd_dist3: the masked launch refused a level set up for it";
 		print_error(m);
 	}
-	halo_exchange(d, L.halo, L.II, L.JJ, L.KK, x, 1, 4);
+	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, across, across, -1, kpar);
 }
 
 void smooth(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int updown, int nsweeps)
@@ -309,6 +318,19 @@ int loop_world = 1;
 int loop_exchange(void *, int ns, const int *, const real_t *const *sbuf, const size_t *scount, int nr, const int *,
                   real_t *const *rbuf, const size_t *rcount)
 {
+	// a grouped send / receive is ONE launch on the RCCL transport: where the receive side mirrors the send side (the halo
+	// buffers do) the stand-in is one copy of the span the messages cover, else one per message
+	bool mirror = ns == nr && ns > 0;
+	const real_t *lo = ns ? sbuf[0] : nullptr, *hi = lo;
+	for (int i = 0; i < ns && mirror; i++) {
+		mirror = scount[i] == rcount[i] && (rbuf[i] - rbuf[0]) == (sbuf[i] - sbuf[0]);
+		if (sbuf[i] < lo) lo = sbuf[i];
+		if (sbuf[i] + scount[i] > hi) hi = sbuf[i] + scount[i];
+	}
+	if (mirror) {
+		cedar_amd_memcpy_d2d(rbuf[0] + (lo - sbuf[0]), lo, (size_t)(hi - lo) * sizeof(real_t));
+		return 0;
+	}
 	for (int i = 0; i < ns && i < nr; i++)
 		cedar_amd_memcpy_d2d(rbuf[i], sbuf[i], (scount[i] < rcount[i] ? scount[i] : rcount[i]) * sizeof(real_t));
 	return 0;

@@ -166,6 +166,45 @@ static inline void halo_exchange(RankCtx *d, Halo &h, int II, int JJ, int KK, re
 	cedar_amd_box_copy(arr, II, JJ, KK, nplanes, nbx, G.rboxes.data(), G.offs.data(), rb, 1);
 }
 
+// The ghost cells of this rank's own z layer / across z that one stage of the boundary-first chain has changed: of the
+// messages selected by `send` / `recv` (neighbour offsets) only the rows with index parity jpar and the planes with index
+// parity kpar (-1: all).  Local extents are even along split directions, so a row or plane has the same parity on both
+// ends of a message and both ends find the same boxes (an empty one is no message).
+template <class FS, class FR>
+static inline void halo_exchange_sub(RankCtx *d, Halo &h, int II, int JJ, int KK, real_t *arr, FS send, FR recv, int jpar, int kpar)
+{
+	if (h.nb.empty()) return;
+	auto &bp = halo_bufs(h, 1, h.total);
+	real_t *sb = bp.first, *rb = bp.second;
+	int sboxes[26 * 8], rboxes[26 * 8], speer[26], rpeer[26], ns = 0, nr = 0;
+	unsigned long long soffs[26], roffs[26];
+	const real_t *sp[26];
+	real_t *rp[26];
+	size_t scnt[26], rcnt[26];
+	auto restrict_box = [&](const int *box, int *out) -> size_t {
+		int j0 = box[1], nj = box[4], sj = 1, k0 = box[2], nk = box[5], sk = 1;
+		if (jpar >= 0) { const int f = ((j0 & 1) == jpar) ? j0 : j0 + 1; nj = (j0 + nj - f + 1) / 2; j0 = f; sj = 2; }
+		if (kpar >= 0) { const int f = ((k0 & 1) == kpar) ? k0 : k0 + 1; nk = (k0 + nk - f + 1) / 2; k0 = f; sk = 2; }
+		if (nj < 0) nj = 0;
+		if (nk < 0) nk = 0;
+		out[0] = box[0]; out[1] = j0; out[2] = k0; out[3] = box[3]; out[4] = nj; out[5] = nk; out[6] = sj; out[7] = sk;
+		return (size_t)box[3] * nj * nk;
+	};
+	for (const HaloEntry &e : h.nb) {
+		if (send(e.o)) {
+			const size_t c = restrict_box(e.sbox, sboxes + 8 * ns);
+			if (c) { speer[ns] = e.peer; soffs[ns] = e.off; sp[ns] = sb + e.off; scnt[ns] = c; ns++; }
+		}
+		if (recv(e.o)) {
+			const size_t c = restrict_box(e.rbox, rboxes + 8 * nr);
+			if (c) { rpeer[nr] = e.peer; roffs[nr] = e.off; rp[nr] = rb + e.off; rcnt[nr] = c; nr++; }
+		}
+	}
+	if (ns) cedar_amd_box_copy_strided(arr, II, JJ, KK, 1, ns, sboxes, soffs, sb, 0);
+	if (tp_exchange(d, ns, speer, sp, scnt, nr, rpeer, rp, rcnt)) { char m[] = "cedar_amd_dist3: halo exchange failed"; print_error(m); }
+	if (nr) cedar_amd_box_copy_strided(arr, II, JJ, KK, 1, nr, rboxes, roffs, rb, 1);
+}
+
 // x faces only (owned j,k): to_minus: first owned column to the -x neighbour, the +x neighbour's into the high ghost
 // column (UP order); else the mirror image.  Returns true if a column was received.
 static inline bool halo_exchange_x(RankCtx *d, Halo &h, int II, int JJ, int KK, real_t *arr, bool to_minus)

@@ -293,6 +293,7 @@ void interp_add3(real_t *q, const real_t *qc, const real_t *so, real_t *res, con
 struct BoxTable {
 	int n;
 	int i0[26], j0[26], k0[26], ni[26], nj[26], nk[26];
+	int sj[26], sk[26]; // step between the rows / planes of a box (1: dense; 2: one row class / one k-parity)
 	unsigned long long off[26]; // offset of the box (first plane) in the buffer, in doubles
 };
 
@@ -306,23 +307,26 @@ __global__ __launch_bounds__(256) void box_copy_kernel(real_t *__restrict__ arr,
 	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < ntot; t += (size_t)gridDim.x * blockDim.x) {
 		const size_t pl = t / nbox, r = t % nbox;
 		const int i = (int)(r % ni), j = (int)((r / ni) % nj), k = (int)(r / ((size_t)ni * nj));
-		const size_t a = pl * PS + (size_t)(tab.i0[bx] + i) + (size_t)II * ((size_t)(tab.j0[bx] + j) + (size_t)JJ * (size_t)(tab.k0[bx] + k));
+		const size_t a = pl * PS + (size_t)(tab.i0[bx] + i) +
+		                 (size_t)II * ((size_t)(tab.j0[bx] + j * tab.sj[bx]) + (size_t)JJ * (size_t)(tab.k0[bx] + k * tab.sk[bx]));
 		const size_t b = tab.off[bx] * (size_t)nplanes + t;
 		if (unpack) arr[a] = buf[b];
 		else buf[b] = arr[a];
 	}
 }
 
-void box_copy(real_t *arr, int II, int JJ, int KK, int nplanes, int nboxes, const int *boxes /* 6 per box */,
-              const unsigned long long *offsets, real_t *buf, int unpack, hipStream_t st)
+void box_copy(real_t *arr, int II, int JJ, int KK, int nplanes, int nboxes, const int *boxes /* 6 (8: + row step, plane step) per box */,
+              const unsigned long long *offsets, real_t *buf, int unpack, hipStream_t st, int strided)
 {
 	if (nboxes <= 0) return;
 	BoxTable tab;
 	tab.n = nboxes;
 	size_t maxn = 1;
+	const int w = strided ? 8 : 6;
 	for (int b = 0; b < nboxes && b < 26; b++) {
-		tab.i0[b] = boxes[6 * b]; tab.j0[b] = boxes[6 * b + 1]; tab.k0[b] = boxes[6 * b + 2];
-		tab.ni[b] = boxes[6 * b + 3]; tab.nj[b] = boxes[6 * b + 4]; tab.nk[b] = boxes[6 * b + 5];
+		tab.i0[b] = boxes[w * b]; tab.j0[b] = boxes[w * b + 1]; tab.k0[b] = boxes[w * b + 2];
+		tab.ni[b] = boxes[w * b + 3]; tab.nj[b] = boxes[w * b + 4]; tab.nk[b] = boxes[w * b + 5];
+		tab.sj[b] = strided ? boxes[w * b + 6] : 1; tab.sk[b] = strided ? boxes[w * b + 7] : 1;
 		tab.off[b] = offsets[b];
 		size_t n = (size_t)tab.ni[b] * tab.nj[b] * tab.nk[b] * nplanes;
 		if (n > maxn) maxn = n;

@@ -245,6 +245,10 @@ void cedar_amd_lines_store2(const real_t *in, real_t *q, len_t ii, len_t jj, int
  * offsets[b]*nplanes .. ).  Device pointers only. */
 void cedar_amd_box_copy(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, int nboxes,
                         const int *boxes, const unsigned long long *offsets, real_t *buf, int unpack);
+/* the same with boxes = {i0,j0,k0,ni,nj,nk,sj,sk}: row j0 + j*sj, plane k0 + k*sk (the rows of one class / planes of one
+ * k-parity of a face: what one stage of the boundary-first chain has changed) */
+void cedar_amd_box_copy_strided(real_t *arr, len_t ii, len_t jj, len_t kk, int nplanes, int nboxes,
+                                const int *boxes, const unsigned long long *offsets, real_t *buf, int unpack);
 
 /* ------------------------------------------------------------------ 2. handle API */
 typedef struct cedar_amd_solver cedar_amd_solver;
