@@ -509,6 +509,19 @@ void cedar_amd_relax3_cols(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t
 	              current_stream());
 }
 
+size_t cedar_amd_relax3_strip_doubles(len_t jj, len_t kk) { return relax3_strip_doubles((int)jj, (int)kk); }
+
+void cedar_amd_relax3_strip_build(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk, int side, real_t *out)
+{
+	relax3_strip_build(so, sor, (int)ii, (int)jj, (int)kk, side, out, current_stream());
+}
+
+void cedar_amd_relax3_cols_strip(const real_t *strip_lo, const real_t *strip_hi, real_t *qf, real_t *q, len_t ii, len_t jj, len_t kk,
+                                 int jb, int kb, int ncol, const int *cols, int xrow0, int xrow1)
+{
+	relax3_cols27_strip(strip_lo, strip_hi, qf, q, (int)ii, (int)jj, (int)kk, jb, kb, ncol, cols, xrow0, xrow1, current_stream());
+}
+
 int cedar_amd_relax3_planes_masked(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int kb,
                                    int up, unsigned cols_f, unsigned cols_s, const int *rows)
 {

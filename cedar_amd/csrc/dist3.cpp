@@ -31,6 +31,7 @@ struct DLevel {
 	size_t npts = 0;
 	real_t *A = nullptr, *P = nullptr, *x = nullptr, *b = nullptr, *res = nullptr, *sor = nullptr;
 	bool ownA = true, overlap = false;
+	real_t *strip[2] = {nullptr, nullptr}; // dense copies of the operator columns next to the low / high x face (chain levels)
 	bool chain = false; // x / y split and the level takes the partial-sum sweep: boundary-first chain + one masked launch per k-parity
 	Halo halo;
 };
@@ -132,6 +133,11 @@ void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, b
 	}
 	const int skip[3] = {nrF > 0 ? rowsF[0] : -1, nrF > 1 ? rowsF[1] : -1, rowS};
 	const bool xs = d->p[0] > 1;
+	auto cols = [&](int jb, int n, const int *cl, int x0, int x1) {
+		if (n <= 0) return;
+		if (L.strip[0] || L.strip[1]) cedar_amd_relax3_cols_strip(L.strip[0], L.strip[1], b, x, L.II, L.JJ, L.KK, jb, kb, n, cl, x0, x1);
+		else cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jb, kb, n, cl, x0, x1);
+	};
 	// what a stage has changed: rows of one class in the planes of the parity; side Q's fixed column travels one way only
 	const int jparF = (1 + jbF) & 1, jparS = (1 + jbS) & 1, kpar = (1 + kb) & 1, qdir = up ? +1 : -1;
 	auto layer = [](const int *o) { return o[2] == 0; };
@@ -143,18 +149,18 @@ void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, b
 	auto not_q = [&](const int *o) { return o[2] == 0 && o[0] != qdir; };
 	// F rows
 	if (nrF) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowsF[0], nrF > 1 ? rowsF[1] - rowsF[0] : 2, nrF, kb, up);
-	if (nF) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbF, kb, nF, colsF, skip[0], skip[1]);
+	cols(jbF, nF, colsF, skip[0], skip[1]);
 	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, jparF, kpar);
 	if (xs) {
-		if (nfix) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbF, kb, nfix, fixc, -1, -1);
+		cols(jbF, nfix, fixc, -1, -1);
 		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, not_p, not_q, jparF, kpar);
 	}
 	// S rows
 	if (rowS >= 0) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowS, 2, 1, kb, up);
-	if (nS) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbS, kb, nS, colsS, rowS, -1);
+	cols(jbS, nS, colsS, rowS, -1);
 	if (xs) {
 		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, to_p, to_q, jparS, kpar); // side P's first colour to the neighbour's side Q
-		if (nfix) cedar_amd_relax3_cols(L.A, b, x, L.sor, L.II, L.JJ, L.KK, jbS, kb, nfix, fixc, -1, -1);
+		cols(jbS, nfix, fixc, -1, -1);
 	}
 	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, jparS, kpar); // ghost columns are sources of the launch's partial sums
 	if (!cedar_amd_relax3_planes_masked(L.A, b, x, L.sor, L.II, L.JJ, L.KK, kb, up, mF, mS, skip)) {
@@ -290,6 +296,12 @@ void setup(cedar_amd_dist3 *d)
 		// (chain_parity); CEDAR_AMD_DIST_CHAIN=0 keeps the reference-order row-class passes
 		else if (F.nst == 14 && F.n[0] >= 8 && F.n[1] >= 8 && !(getenv("CEDAR_AMD_DIST_CHAIN") && !atoi(getenv("CEDAR_AMD_DIST_CHAIN"))))
 			F.chain = (cedar_amd_relax3_prepare(F.A, F.sor, F.II, F.JJ, F.KK) & 2) != 0;
+		if (F.chain && F.n[0] >= 12 && !(getenv("CEDAR_AMD_DIST_STRIP") && !atoi(getenv("CEDAR_AMD_DIST_STRIP"))))
+			for (int side = 0; side < 2; side++)
+				if (has_nb(d, 0, side ? +1 : -1)) {
+					F.strip[side] = dmalloc(cedar_amd_relax3_strip_doubles(F.JJ, F.KK));
+					cedar_amd_relax3_strip_build(F.A, F.sor, F.II, F.JJ, F.KK, side, F.strip[side]);
+				}
 	}
 	// level la: the global operator on every rank; the single-domain device-resident solver takes over from there
 	DLevel &C = d->lv.back();
@@ -486,6 +498,7 @@ void cedar_amd_dist3_destroy(cedar_amd_dist3 *d)
 	for (DLevel &L : d->lv) {
 		if (L.ownA) cedar_amd_free(L.A);
 		else if (L.A) cedar_amd_relax3_release(L.A); // the caller's operator: only its registered solve copy goes
+		cedar_amd_free(L.strip[0]); cedar_amd_free(L.strip[1]);
 		cedar_amd_free(L.P); cedar_amd_free(L.x); cedar_amd_free(L.b); cedar_amd_free(L.res); cedar_amd_free(L.sor);
 		for (auto &kv : L.halo.bufs) { cedar_amd_free(kv.second.first); cedar_amd_free(kv.second.second); }
 	}

@@ -45,6 +45,11 @@ void relax3_rows27(const real_t *so, const real_t *qf, real_t *q, const real_t *
                    int nrj, int kb, int efirst, hipStream_t st);
 void relax3_cols27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int KK, int jb, int kb,
                    int ncol, const int *cols, int xrow0, int xrow1, hipStream_t st);
+// the column stage on a dense copy of the six operator columns next to an x face (side 0 low / 1 high; out: relax3_strip_doubles)
+size_t relax3_strip_doubles(int JJ, int KK);
+void relax3_strip_build(const real_t *so, const real_t *sor, int II, int JJ, int KK, int side, real_t *out, hipStream_t st);
+void relax3_cols27_strip(const real_t *strip_lo, const real_t *strip_hi, const real_t *qf, real_t *q, int II, int JJ, int KK, int jb,
+                         int kb, int ncol, const int *cols, int xrow0, int xrow1, hipStream_t st);
 // run length of the partial-sum sweep on a level with JJ-2 rows (0 = the level keeps the reference order), relax3d.hip
 int relax3_psum_frun(int JJ);
 

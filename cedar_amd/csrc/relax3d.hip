@@ -597,6 +597,98 @@ __global__ void relax27_cols(const Op3 A, const real_t *__restrict__ qf, real_t 
 	}
 }
 
+// The same from a dense copy of the operator's six columns next to an x face (relax3_strip_build): the column kernel
+// above fetches a 128-byte line for every 8-byte entry it uses (55 lines per point; 0.1 ms per stage at 512^3, 2.5 ms per
+// V-cycle); here the 25 coefficient segments of a point and 1/diag are 48-byte pieces of an array laid out
+// [slot][k][j][6 columns], so neighbouring rows share lines.  q and the right-hand side stay where they are.
+// Window: offsets 0..5 (low side) or II-6..II-1 (high side); slot 14 = 1/diag.
+struct StripRef {
+	const real_t *lo, *hi;
+};
+constexpr int STRIP_W = 6, STRIP_SLOTS = 15;
+
+__device__ __forceinline__ real_t strip_at(const real_t *__restrict__ S, int JJ, int KK, int slot, size_t j, size_t k, int w)
+{
+	return S[(((size_t)slot * KK + k) * JJ + j) * STRIP_W + w];
+}
+
+__global__ void relax27_cols_strip(StripRef sr, const real_t *__restrict__ qf, real_t *q, int II, int JJ, int KK, int jb, int kb,
+                                   ChainCols cc)
+{
+	const int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nj * nk) return;
+	const int jr = 1 + jb + 2 * (t % nj);
+	if (jr == cc.xrow[0] || jr == cc.xrow[1]) return;
+	const size_t j = (size_t)jr, k = (size_t)(1 + kb + 2 * (t / nj));
+	const size_t sj = II, sk = (size_t)II * JJ;
+	for (int cidx = 0; cidx < cc.n; cidx++) {
+		const int i = cc.col[cidx];
+		const bool low = i < II / 2;
+		const real_t *__restrict__ S = low ? sr.lo : sr.hi;
+		const int w = low ? i : i - (II - STRIP_W);
+		C27 c;
+#define SA(slot, dj, dk, dw) strip_at(S, JJ, KK, slot, j + dj, k + dk, w + dw)
+		c.pw = SA(KPW, 0, 0, 0); c.ps = SA(KPS, 0, 0, 0); c.psw = SA(KPSW, 0, 0, 0);
+		c.b = SA(KB, 0, 0, 0); c.bw = SA(KBW, 0, 0, 0); c.bs = SA(KBS, 0, 0, 0); c.bsw = SA(KBSW, 0, 0, 0);
+		c.pnw_n = SA(KPNW, 1, 0, 0); c.ps_n = SA(KPS, 1, 0, 0); c.bnw_n = SA(KBNW, 1, 0, 0); c.bn_n = SA(KBN, 1, 0, 0);
+		c.b_t = SA(KB, 0, 1, 0); c.be_t = SA(KBE, 0, 1, 0); c.bn_t = SA(KBN, 0, 1, 0); c.bne_t = SA(KBNE, 0, 1, 0);
+		c.bse_nt = SA(KBSE, 1, 1, 0); c.bs_nt = SA(KBS, 1, 1, 0);
+		c.psw_ne = SA(KPSW, 1, 0, 1); c.bne_ne = SA(KBNE, 1, 0, 1);
+		c.pw_e = SA(KPW, 0, 0, 1); c.pnw_e = SA(KPNW, 0, 0, 1); c.be_e = SA(KBE, 0, 0, 1); c.bse_e = SA(KBSE, 0, 0, 1);
+		c.bsw_net = SA(KBSW, 1, 1, 1);
+		c.bw_et = SA(KBW, 0, 1, 1); c.bnw_et = SA(KBNW, 0, 1, 1);
+		const real_t rd = SA(14, 0, 0, 0);
+#undef SA
+		const size_t x = (size_t)i + sj * j + sk * k;
+		real_t qq[3][3][3];
+#pragma unroll
+		for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+			for (int dj = 0; dj < 3; dj++)
+#pragma unroll
+				for (int di = 0; di < 3; di++)
+					qq[dk][dj][di] = q[x + (di - 1) + (ptrdiff_t)(dj - 1) * (ptrdiff_t)sj + (ptrdiff_t)(dk - 1) * (ptrdiff_t)sk];
+		q[x] = offdiag27(qf[x], c, qq) * rd;
+	}
+}
+
+// dense copy of the six columns next to the low (side 0) / high (side 1) x face: out[15][KK][JJ][6] (slot 14 = 1/diag, sor's second plane)
+__global__ void strip_build_kernel(const real_t *__restrict__ so, const real_t *__restrict__ sor, real_t *__restrict__ out,
+                                   int II, int JJ, int KK, int w0)
+{
+	const size_t n = (size_t)STRIP_SLOTS * KK * JJ * STRIP_W, PS = (size_t)II * JJ * KK;
+	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+		const int w = (int)(t % STRIP_W);
+		const size_t r = t / STRIP_W, j = r % JJ, k = (r / JJ) % KK, slot = r / ((size_t)JJ * KK);
+		const size_t x = (size_t)(w0 + w) + (size_t)II * (j + (size_t)JJ * k);
+		out[t] = slot < 14 ? so[slot * PS + x] : sor[PS + x]; // SOR plane msor = 1/diag (op3_cedar)
+	}
+}
+
+size_t relax3_strip_doubles(int JJ, int KK) { return (size_t)STRIP_SLOTS * KK * JJ * STRIP_W; }
+
+void relax3_strip_build(const real_t *so, const real_t *sor, int II, int JJ, int KK, int side, real_t *out, hipStream_t st)
+{
+	if (II < 2 * STRIP_W) return;
+	hipLaunchKernelGGL(strip_build_kernel, dim3(cap_grid(relax3_strip_doubles(JJ, KK), 256)), dim3(256), 0, st, so, sor, out, II, JJ,
+	                   KK, side ? II - STRIP_W : 0);
+}
+
+void relax3_cols27_strip(const real_t *strip_lo, const real_t *strip_hi, const real_t *qf, real_t *q, int II, int JJ, int KK, int jb,
+                         int kb, int ncol, const int *cols, int xrow0, int xrow1, hipStream_t st)
+{
+	const int nj = (JJ - 2 - jb + 1) / 2, nk = (KK - 2 - kb + 1) / 2;
+	if (nj <= 0 || nk <= 0 || ncol <= 0) return;
+	ChainCols cc;
+	cc.n = ncol < 8 ? ncol : 8;
+	for (int c = 0; c < 8; c++) cc.col[c] = c < cc.n ? cols[c] : 1;
+	cc.xrow[0] = xrow0; cc.xrow[1] = xrow1;
+	StripRef sr;
+	sr.lo = strip_lo; sr.hi = strip_hi;
+	hipLaunchKernelGGL(relax27_cols_strip, dim3((nj * nk + 63) / 64), dim3(64), 0, st, sr, qf, q, II, JJ, KK, jb, kb, cc);
+}
+
 void relax3_cols27(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int KK, int jb, int kb,
                    int ncol, const int *cols, int xrow0, int xrow1, hipStream_t st)
 {

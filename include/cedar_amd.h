@@ -208,6 +208,14 @@ void cedar_amd_relax3_cols(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t
                            int ncol, const int *cols, int xrow0, int xrow1);
 int cedar_amd_relax3_planes_masked(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk, int kb,
                                    int up, unsigned cols_f, unsigned cols_s, const int *rows);
+/* _cols on a dense copy of the six operator columns next to an x face (device pointers only; at least 12 columns per row):
+ * _strip_build fills out[_strip_doubles(jj,kk)] for the low (side 0: columns 0..5) or the high (side 1: ii-6..ii-1) face from
+ * the operator and its SETUP_recip output; _cols_strip takes the copies of the sides its columns lie on (the other may be
+ * NULL).  Same arithmetic as _cols, a fraction of its memory traffic. */
+size_t cedar_amd_relax3_strip_doubles(len_t jj, len_t kk);
+void cedar_amd_relax3_strip_build(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk, int side, real_t *out);
+void cedar_amd_relax3_cols_strip(const real_t *strip_lo, const real_t *strip_hi, real_t *qf, real_t *q, len_t ii, len_t jj, len_t kk,
+                                 int jb, int kb, int ncol, const int *cols, int xrow0, int xrow1);
 /* one colour of the 7-point red-black sweep (pts = 0|1, BMG3_SymStd_relax_GS.f90:155-184) */
 void cedar_amd_relax3_colour7(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, len_t kk,
                               int pts);

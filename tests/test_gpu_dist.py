@@ -134,8 +134,8 @@ def test_native_driver_ranks_sharing_one_gpu_equal_single_domain(n, pgrid, overl
 # points qualify): boundary-first chain + one masked launch per k-parity (dist3.cpp chain_parity).  Every role of a rank:
 # neighbour on the low / high / both sides in x and in y, with and without a z split.
 CHAIN_CASES = [((16, 32, 8), (2, 2, 1)), ((16, 16, 8), (3, 1, 1)), ((8, 24, 8), (1, 3, 1)), ((16, 16, 8), (2, 1, 2)),
-               ((8, 16, 8), (1, 2, 2)), ((32, 32, 16), (2, 2, 1))]
-CHAIN_IDS = ["4ranks-xy", "3ranks-x", "3ranks-y", "4ranks-xz", "4ranks-yz", "4ranks-xy-two-chain-levels"]
+               ((8, 16, 8), (1, 2, 2)), ((32, 32, 16), (2, 2, 1)), ((8, 16, 8), (2, 2, 1))]
+CHAIN_IDS = ["4ranks-xy", "3ranks-x", "3ranks-y", "4ranks-xz", "4ranks-yz", "4ranks-xy-two-chain-levels", "4ranks-xy-8-columns"]
 
 
 @pytest.mark.parametrize("n,pgrid", CHAIN_CASES, ids=CHAIN_IDS)
