@@ -94,8 +94,8 @@ void gather_into(cedar_amd_dist3 *d, real_t *local, int lII, int lJJ, int lKK, i
 //   chain, side Q: F c1 {d1,d3}, F c2 {d0,d2}, S c1 {d1}, S c2 {d0};   side P: F c1 {d0,d2}, F c2 {d1}, S c1 {d0}
 //   side P of y: its boundary row is an F row (UP: the low side): that row;   side Q: F row d1, S row d0 (whole rows)
 // Both colours of a row class run in one kernel with the ghost column of side Q still stale: its c2 column d0 is
-// recomputed after the exchange (nobody has read it in between) -- four exchanges within the rank's z layer per parity,
-// then the launch, then the exchange across z.
+// recomputed after the exchange (nobody has read it in between) -- three exchanges within the rank's z layer per parity
+// (one without an x split), each restricted to what the stage changed, then the launch, then one exchange with everything else.
 void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, bool up)
 {
 	const int nx = L.n[0], ny = L.n[1];
@@ -141,7 +141,6 @@ void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, b
 	// what a stage has changed: rows of one class in the planes of the parity; side Q's fixed column travels one way only
 	const int jparF = (1 + jbF) & 1, jparS = (1 + jbS) & 1, kpar = (1 + kb) & 1, qdir = up ? +1 : -1;
 	auto layer = [](const int *o) { return o[2] == 0; };
-	auto across = [](const int *o) { return o[2] != 0; };
 	auto to_q = [&](const int *o) { return o[2] == 0 && o[0] == qdir; };
 	auto to_p = [&](const int *o) { return o[2] == 0 && o[0] == -qdir; };
 	// the fixed column also sits in the boundary row a y neighbour has already received: everything but the messages across side P
@@ -150,24 +149,30 @@ void chain_parity(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int kb, b
 	// F rows
 	if (nrF) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowsF[0], nrF > 1 ? rowsF[1] - rowsF[0] : 2, nrF, kb, up);
 	cols(jbF, nF, colsF, skip[0], skip[1]);
-	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, jparF, kpar);
+	auto rowsF_only = [&](const int *) { return jparF; };
+	auto rowsS_only = [&](const int *) { return jparS; };
+	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, rowsF_only, kpar);
 	if (xs) {
 		cols(jbF, nfix, fixc, -1, -1);
-		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, not_p, not_q, jparF, kpar);
+		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, not_p, not_q, rowsF_only, kpar);
 	}
 	// S rows
 	if (rowS >= 0) cedar_amd_relax3_rows(L.A, b, x, L.sor, L.II, L.JJ, L.KK, rowS, 2, 1, kb, up);
 	cols(jbS, nS, colsS, rowS, -1);
 	if (xs) {
-		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, to_p, to_q, jparS, kpar); // side P's first colour to the neighbour's side Q
+		halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, to_p, to_q, rowsS_only, kpar); // side P's first colour to the neighbour's side Q
 		cols(jbS, nfix, fixc, -1, -1);
 	}
-	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, layer, layer, jparS, kpar); // ghost columns are sources of the launch's partial sums
+	// The launch reads no ghost cell of the rank's own z layer: only the points of a boundary column / row do, and those are
+	// chain points (its ghost-column sources feed partial sums of column d0 in the planes of the other parity -- chain points
+	// again, relaxed from the operator).  The S rows therefore travel with the exchange across z after the launch.
 	if (!cedar_amd_relax3_planes_masked(L.A, b, x, L.sor, L.II, L.JJ, L.KK, kb, up, mF, mS, skip)) {
 		char m[] = "cedar_amd_dist3: the masked launch refused a level set up for it";
 		print_error(m);
 	}
-	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, across, across, -1, kpar);
+	auto all = [](const int *) { return true; };
+	auto rows_last = [&](const int *o) { return o[2] == 0 ? jparS : -1; };
+	halo_exchange_sub(d, L.halo, L.II, L.JJ, L.KK, x, all, all, rows_last, kpar);
 }
 
 void smooth(cedar_amd_dist3 *d, DLevel &L, real_t *x, real_t *b, int updown, int nsweeps)

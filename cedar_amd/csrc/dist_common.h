@@ -167,11 +167,11 @@ static inline void halo_exchange(RankCtx *d, Halo &h, int II, int JJ, int KK, re
 }
 
 // The ghost cells of this rank's own z layer / across z that one stage of the boundary-first chain has changed: of the
-// messages selected by `send` / `recv` (neighbour offsets) only the rows with index parity jpar and the planes with index
-// parity kpar (-1: all).  Local extents are even along split directions, so a row or plane has the same parity on both
+// messages selected by `send` / `recv` (neighbour offsets) only the rows with index parity jpar_of(offset) and the planes
+// with index parity kpar (-1: all).  Local extents are even along split directions, so a row or plane has the same parity on both
 // ends of a message and both ends find the same boxes (an empty one is no message).
-template <class FS, class FR>
-static inline void halo_exchange_sub(RankCtx *d, Halo &h, int II, int JJ, int KK, real_t *arr, FS send, FR recv, int jpar, int kpar)
+template <class FS, class FR, class FJ>
+static inline void halo_exchange_sub(RankCtx *d, Halo &h, int II, int JJ, int KK, real_t *arr, FS send, FR recv, FJ jpar_of, int kpar)
 {
 	if (h.nb.empty()) return;
 	auto &bp = halo_bufs(h, 1, h.total);
@@ -181,7 +181,7 @@ static inline void halo_exchange_sub(RankCtx *d, Halo &h, int II, int JJ, int KK
 	const real_t *sp[26];
 	real_t *rp[26];
 	size_t scnt[26], rcnt[26];
-	auto restrict_box = [&](const int *box, int *out) -> size_t {
+	auto restrict_box = [&](const int *box, int *out, int jpar) -> size_t {
 		int j0 = box[1], nj = box[4], sj = 1, k0 = box[2], nk = box[5], sk = 1;
 		if (jpar >= 0) { const int f = ((j0 & 1) == jpar) ? j0 : j0 + 1; nj = (j0 + nj - f + 1) / 2; j0 = f; sj = 2; }
 		if (kpar >= 0) { const int f = ((k0 & 1) == kpar) ? k0 : k0 + 1; nk = (k0 + nk - f + 1) / 2; k0 = f; sk = 2; }
@@ -192,11 +192,11 @@ static inline void halo_exchange_sub(RankCtx *d, Halo &h, int II, int JJ, int KK
 	};
 	for (const HaloEntry &e : h.nb) {
 		if (send(e.o)) {
-			const size_t c = restrict_box(e.sbox, sboxes + 8 * ns);
+			const size_t c = restrict_box(e.sbox, sboxes + 8 * ns, jpar_of(e.o));
 			if (c) { speer[ns] = e.peer; soffs[ns] = e.off; sp[ns] = sb + e.off; scnt[ns] = c; ns++; }
 		}
 		if (recv(e.o)) {
-			const size_t c = restrict_box(e.rbox, rboxes + 8 * nr);
+			const size_t c = restrict_box(e.rbox, rboxes + 8 * nr, jpar_of(e.o));
 			if (c) { rpeer[nr] = e.peer; roffs[nr] = e.off; rp[nr] = rb + e.off; rcnt[nr] = c; nr++; }
 		}
 	}
