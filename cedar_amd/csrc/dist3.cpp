@@ -299,7 +299,8 @@ void setup(cedar_amd_dist3 *d)
 		if (F.nst == 14 && d->p[0] == 1 && d->p[1] == 1) cedar_amd_relax3_prepare(F.A, F.sor, F.II, F.JJ, F.KK);
 		// x / y split: where the level takes the partial-sum sweep (scratch registered: bit 1), the boundary-first chain
 		// (chain_parity); CEDAR_AMD_DIST_CHAIN=0 keeps the reference-order row-class passes
-		else if (F.nst == 14 && F.n[0] >= 8 && F.n[1] >= 8 && !(getenv("CEDAR_AMD_DIST_CHAIN") && !atoi(getenv("CEDAR_AMD_DIST_CHAIN"))))
+		else if (F.nst == 14 && F.n[0] >= 8 && F.n[1] >= 8 && !(getenv("CEDAR_AMD_DIST_CHAIN") && !atoi(getenv("CEDAR_AMD_DIST_CHAIN"))) &&
+		         F.n[1] >= (getenv("CEDAR_AMD_DIST_CHAIN_MIN") ? atoi(getenv("CEDAR_AMD_DIST_CHAIN_MIN")) : 0))
 			F.chain = (cedar_amd_relax3_prepare(F.A, F.sor, F.II, F.JJ, F.KK) & 2) != 0;
 		if (F.chain && F.n[0] >= 12 && !(getenv("CEDAR_AMD_DIST_STRIP") && !atoi(getenv("CEDAR_AMD_DIST_STRIP"))))
 			for (int side = 0; side < 2; side++)
