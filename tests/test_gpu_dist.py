@@ -138,13 +138,19 @@ CHAIN_CASES = [((16, 32, 8), (2, 2, 1)), ((16, 16, 8), (3, 1, 1)), ((8, 24, 8), 
 CHAIN_IDS = ["4ranks-xy", "3ranks-x", "3ranks-y", "4ranks-xz", "4ranks-yz", "4ranks-xy-two-chain-levels", "4ranks-xy-8-columns"]
 
 
+# the production run length (16 rows from 224 rows per box on) on a 2 x 2 x 1 grid
+CHAIN_CASES.append(((64, 256, 32), (2, 2, 1)))  # (z deep enough for a four-level hierarchy: the coarsest level is solved directly)
+CHAIN_IDS.append("4ranks-xy-default-run-length")
+
+
 @pytest.mark.parametrize("n,pgrid", CHAIN_CASES, ids=CHAIN_IDS)
 def test_native_driver_boundary_first_chain_equals_single_domain(n, pgrid, tmp_path, oracle, monkeypatch):
     """the partial-sum sweep on rank grids with an x / y split: columns and rows next to a neighbouring rank relaxed ahead,
     stage by stage, the rest of a k-parity in one masked launch -- the single-domain history and solution"""
-    monkeypatch.setenv("CEDAR_AMD_FRUN", "2")
+    if n[1] < 256:
+        monkeypatch.setenv("CEDAR_AMD_FRUN", "2")
     world = pgrid[0] * pgrid[1] * pgrid[2]
-    two = n[0] >= 32  # levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered), both on the chain
+    two = n == (32, 32, 16)  # levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered), both on the chain
     _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), 96, "native", 4 if two else 64))
     assert int(open(tmp_path / "chain_levels.txt").read()) == (2 if two else 1)
     _check_against_single_domain(n, pgrid, tmp_path, oracle)
