@@ -600,16 +600,23 @@ __global__ void relax27_cols(const Op3 A, const real_t *__restrict__ qf, real_t 
 // The same from a dense copy of the operator's six columns next to an x face (relax3_strip_build): the column kernel
 // above fetches a 128-byte line for every 8-byte entry it uses (55 lines per point; 0.1 ms per stage at 512^3, 2.5 ms per
 // V-cycle); here the 25 coefficient segments of a point and 1/diag are 48-byte pieces of an array laid out
-// [slot][k][j][6 columns], so neighbouring rows share lines.  q and the right-hand side stay where they are.
+// [slot][k][j parity][j / 2][6 columns], so the rows of a stage share lines.  q and the right-hand side stay where they are.
 // Window: offsets 0..5 (low side) or II-6..II-1 (high side); slot 14 = 1/diag.
 struct StripRef {
 	const real_t *lo, *hi;
 };
 constexpr int STRIP_W = 6, STRIP_SLOTS = 15;
 
+// rows of one j-parity are contiguous: the lanes of a stage (rows of one class) read 48-byte pieces back to back, from the
+// own class for entries stored at row j and from the other class for those stored at row j+1
+__host__ __device__ __forceinline__ size_t strip_index(int JJ, int KK, size_t slot, size_t j, size_t k, int w)
+{
+	const size_t JH = ((size_t)JJ + 1) / 2;
+	return ((((slot * KK + k) * 2 + (j & 1)) * JH + (j >> 1)) * STRIP_W) + w;
+}
 __device__ __forceinline__ real_t strip_at(const real_t *__restrict__ S, int JJ, int KK, int slot, size_t j, size_t k, int w)
 {
-	return S[(((size_t)slot * KK + k) * JJ + j) * STRIP_W + w];
+	return S[strip_index(JJ, KK, (size_t)slot, j, k, w)];
 }
 
 __global__ void relax27_cols_strip(StripRef sr, const real_t *__restrict__ qf, real_t *q, int II, int JJ, int KK, int jb, int kb,
@@ -662,11 +669,11 @@ __global__ void strip_build_kernel(const real_t *__restrict__ so, const real_t *
 		const int w = (int)(t % STRIP_W);
 		const size_t r = t / STRIP_W, j = r % JJ, k = (r / JJ) % KK, slot = r / ((size_t)JJ * KK);
 		const size_t x = (size_t)(w0 + w) + (size_t)II * (j + (size_t)JJ * k);
-		out[t] = slot < 14 ? so[slot * PS + x] : sor[PS + x]; // SOR plane msor = 1/diag (op3_cedar)
+		out[strip_index(JJ, KK, slot, j, k, w)] = slot < 14 ? so[slot * PS + x] : sor[PS + x]; // SOR plane msor = 1/diag (op3_cedar)
 	}
 }
 
-size_t relax3_strip_doubles(int JJ, int KK) { return (size_t)STRIP_SLOTS * KK * JJ * STRIP_W; }
+size_t relax3_strip_doubles(int JJ, int KK) { return (size_t)STRIP_SLOTS * KK * 2 * (((size_t)JJ + 1) / 2) * STRIP_W; }
 
 void relax3_strip_build(const real_t *so, const real_t *sor, int II, int JJ, int KK, int side, real_t *out, hipStream_t st)
 {

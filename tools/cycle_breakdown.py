@@ -7,7 +7,10 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "residual27_rows<256"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+top = max(dur(rows[i]) for i in idx)
+idx = [i for i in idx if dur(rows[i]) > top // 2]  # the finest level's launches of the marker kernel
 a, b = idx[-2], idx[-1]
 cyc = rows[a:b]
 t0, t1 = int(cyc[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])
