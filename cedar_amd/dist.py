@@ -171,6 +171,38 @@ class Halo:
                     [(e[1], rb, e[5] * nplanes, e[4] * nplanes) for e in nb])
         self.be.box_copy(arr, nplanes, rboxes, offs, rb, 1)
 
+    def exchange_sub(self, arr, send, recv, jpar_of, kpar):
+        """what one stage of the boundary-first chain has changed (dist3.cpp halo_exchange_sub): of the messages selected
+        by send(o) / recv(o) (o = neighbour offset) only the rows with index parity jpar_of(o) and the planes with index
+        parity kpar (-1: all).  Local extents are even along split directions, so both ends of a message find the same
+        boxes; an empty box is no message.  Boxes carry the row / plane step as entries 6, 7."""
+        def restrict(box, jpar):
+            i0, j0, k0, ni, nj, nk = box
+            sj = sk = 1
+            if jpar >= 0:
+                f = j0 if (j0 & 1) == jpar else j0 + 1
+                nj, j0, sj = max((j0 + nj - f + 1) // 2, 0), f, 2
+            if kpar >= 0:
+                f = k0 if (k0 & 1) == kpar else k0 + 1
+                nk, k0, sk = max((k0 + nk - f + 1) // 2, 0), f, 2
+            return (i0, j0, k0, ni, nj, nk, sj, sk), ni * nj * nk
+        sb, rb = self._buffers(1, self.total)
+        sboxes, soffs, sends, rboxes, roffs, recvs = [], [], [], [], [], []
+        for o, peer, sbox, rbox, _size, off in self.nb:
+            if send(o):
+                bx, c = restrict(sbox, jpar_of(o))
+                if c:
+                    sboxes.append(bx); soffs.append(off); sends.append((peer, sb, off, c))
+            if recv(o):
+                bx, c = restrict(rbox, jpar_of(o))
+                if c:
+                    rboxes.append(bx); roffs.append(off); recvs.append((peer, rb, off, c))
+        if sboxes:
+            self.be.box_copy(arr, 1, sboxes, soffs, sb, 0)
+        self.be.p2p(sends, recvs)
+        if rboxes:
+            self.be.box_copy(arr, 1, rboxes, roffs, rb, 1)
+
     def exchange_x(self, arr, to_minus):
         """x faces only (owned j,k).  to_minus: send the first owned column to the -x neighbour and
         receive the +x neighbour's into the high ghost column (UP order); else the mirror image."""
@@ -358,7 +390,7 @@ class DistSolver3:
     """cedar::cdr3::mpi::solver equivalent for Dirichlet problems, point relaxation, V(pre,post)."""
 
     def __init__(self, backend, topo, A_local, nrelax_pre=2, nrelax_post=1, min_coarse=3, max_iter=10, tol=1e-8,
-                 agglomerate_below=64, overlap_min=96):
+                 agglomerate_below=64, overlap_min=96, chain=False):
         """A_local: (nst, nz+2, ny+2, nx+2) local part of the global operator (ghost layers are
         filled here by exchange; entries coupling to a neighbouring rank must be present)."""
         self.be, self.topo = backend, topo
@@ -366,6 +398,11 @@ class DistSolver3:
         self.pre, self.post, self.max_iter, self.tol = nrelax_pre, nrelax_post, max_iter, tol
         self.min_coarse = min_coarse
         self.overlap_min = overlap_min
+        # chain: rank grids with an x / y split relax a k-parity as the native driver does where the level takes the
+        # partial-sum sweep (dist3.cpp chain_parity): the points next to a neighbouring rank ahead, stage by stage, the rest
+        # in one go.  Here it is the statement of that ORDER on a backend with relax_colour_masked (the CPU backend: every
+        # update in the reference's arithmetic, so the run must equal the single-domain run like any other).
+        self.chain = bool(chain) and (topo.p[0] > 1 or topo.p[1] > 1)
         # faces of the box with a neighbouring rank (bit 0 -y, 1 +y, 2 -z, 3 +z): only rows next to those wait for a halo
         self.sides = (int(topo.has(1, -1)) | int(topo.has(1, +1)) << 1 | int(topo.has(2, -1)) << 2 | int(topo.has(2, +1)) << 3)
         nst = A_local.shape[0]
@@ -477,6 +514,10 @@ class DistSolver3:
                     L.halo.exchange(x)
                 continue
             up = updown == UP
+            if self.chain and L.n[0] >= 8 and L.n[1] >= 8:
+                for c in range(2):
+                    self._chain_parity(L, x, b, c if up else 1 - c, up)
+                continue
             if t.p[0] == 1 and t.p[1] == 1:
                 # slab decomposition: the second row class of a plane needs nothing from another rank, so the
                 # unit between two exchanges is a whole k-parity (plane-fused kernel on big levels); its
@@ -520,6 +561,91 @@ class DistSolver3:
                     L.halo.exchange(x)
         if pending is not None:
             be.wait(pending)
+
+    def _chain_parity(self, L, x, b, kb, up):
+        """One k-parity of planes, boundary-first (cedar_amd/csrc/dist3.cpp chain_parity, same sets, same exchanges).
+        Colours of a parity in sweep order: F rows c1, F rows c2, S rows c1, S rows c2 (c1 = the i-colour relaxed first).
+        d = distance of a column from the x face.  Side Q (boundary column is c2): F c1 {d1,d3}, F c2 {d0,d2}, S c1 {d1},
+        S c2 {d0}; side P (boundary column is c1): F c1 {d0,d2}, F c2 {d1}, S c1 {d0}.  y: the side whose boundary row is an
+        F row: that row; the other side: its F row d1 and its S row d0.  Both colours of a row class run with side Q's
+        ghost column still stale; its c2 column d0 is recomputed after the exchange (nobody has read it)."""
+        import numpy as np
+        be, t = self.be, self.topo
+        nx, ny, nz = L.n
+        jbF = 0 if up else 1
+        jbS = 1 - jbF
+        ib1 = 0 if up else 1  # i-colour relaxed first: offsets 1 + ib + 2a
+        ib2 = 1 - ib1
+        F1, F2, S1, S2, fixc = [], [], [], [], []
+        for side in (0, 1):
+            if not t.has(0, +1 if side else -1):
+                continue
+            is_p = (side == 0) == up
+            col = (lambda d: nx - d) if side else (lambda d: 1 + d)
+            if is_p:
+                F1 += [col(0), col(2)]; F2 += [col(1)]; S1 += [col(0)]
+            else:
+                F1 += [col(1), col(3)]; F2 += [col(0), col(2)]; S1 += [col(1)]; S2 += [col(0)]; fixc += [col(0)]
+        rowsF, rowS = [], None
+        for side in (0, 1):
+            if not t.has(1, +1 if side else -1):
+                continue
+            is_p = (side == 0) == up
+            row = (lambda d: ny - d) if side else (lambda d: 1 + d)
+            if is_p:
+                rowsF.append(row(0))
+            else:
+                rowsF.append(row(1)); rowS = row(0)
+        shape = (nz + 2, ny + 2, nx + 2)
+        ks = slice(1 + kb, nz + 1, 2)
+
+        def points(jb, cols, rows, ib):
+            """mask: the listed columns in every row of class jb, and the listed rows whole -- colour ib only"""
+            m = np.zeros(shape, dtype=bool)
+            for c in cols:
+                m[ks, 1 + jb:ny + 1:2, c] = True
+            for r in rows:
+                m[ks, r, 1:nx + 1] = True
+            keep = np.zeros(shape, dtype=bool)
+            keep[:, :, 1 + ib:nx + 1:2] = True
+            return m & keep
+
+        def colour(ib, jb):
+            return 1 + ib + 2 * jb + 4 * kb
+
+        xs = t.p[0] > 1
+        jparF, jparS, kpar, qdir = (1 + jbF) & 1, (1 + jbS) & 1, (1 + kb) & 1, (1 if up else -1)
+        layer = lambda o: o[2] == 0
+        not_p = lambda o: o[2] == 0 and o[0] != -qdir
+        not_q = lambda o: o[2] == 0 and o[0] != qdir
+        to_p = lambda o: o[2] == 0 and o[0] == -qdir
+        to_q = lambda o: o[2] == 0 and o[0] == qdir
+        every = lambda o: True
+        skip = np.zeros(shape, dtype=bool)
+        # F rows: both colours, side Q's ghost column stale
+        for ib, cols in ((ib1, F1), (ib2, F2)):
+            m = points(jbF, cols, rowsF, ib)
+            skip |= m
+            be.relax_colour_masked(L.A, b, x, L.sor, colour(ib, jbF), m)
+        L.halo.exchange_sub(x, layer, layer, lambda o: jparF, kpar)
+        if xs:
+            be.relax_colour_masked(L.A, b, x, L.sor, colour(ib2, jbF), points(jbF, fixc, [], ib2))
+            # the recomputed column also sits in the boundary row a y neighbour has already received
+            L.halo.exchange_sub(x, not_p, not_q, lambda o: jparF, kpar)
+        # S rows
+        rS = [rowS] if rowS is not None else []
+        for ib, cols in ((ib1, S1), (ib2, S2)):
+            m = points(jbS, cols, rS, ib)
+            skip |= m
+            be.relax_colour_masked(L.A, b, x, L.sor, colour(ib, jbS), m)
+        if xs:
+            L.halo.exchange_sub(x, to_p, to_q, lambda o: jparS, kpar)
+            be.relax_colour_masked(L.A, b, x, L.sor, colour(ib2, jbS), points(jbS, fixc, [], ib2))
+        # everything else of the parity; it reads no ghost cell of the rank's own z layer
+        for jb in (jbF, jbS):
+            for ib in (ib1, ib2):
+                be.relax_colour_masked(L.A, b, x, L.sor, colour(ib, jb), ~skip)
+        L.halo.exchange_sub(x, every, every, lambda o: jparS if o[2] == 0 else -1, kpar)
 
     def _coarse_solve(self, x, b):
         """levels la.. : gather the right-hand side, one single-domain cycle (or the direct solve when

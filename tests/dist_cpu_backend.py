@@ -30,8 +30,9 @@ class CpuBackend:
 
     @staticmethod
     def _view(arr, box):
-        i0, j0, k0, ni, nj, nk = box
-        return arr[..., k0:k0 + nk, j0:j0 + nj, i0:i0 + ni]
+        i0, j0, k0, ni, nj, nk = box[:6]
+        sj, sk = (box[6], box[7]) if len(box) == 8 else (1, 1)  # row / plane step (cedar_amd_box_copy_strided)
+        return arr[..., k0:k0 + nk * sk:sk, j0:j0 + nj * sj:sj, i0:i0 + ni]
 
     def box_copy(self, arr, nplanes, boxes, offs, buf, unpack):
         # buffer layout of cedar_amd_box_copy: box b at offs[b]*nplanes, plane-major inside
@@ -76,6 +77,15 @@ class CpuBackend:
         for jb in ((0, 1) if up else (1, 0)):
             for ib in ((0, 1) if up else (1, 0)):
                 self.O.relax_colour3_part(self._n(A), self._n(b), self._n(x), self._n(sor), 1 + ib + 2 * jb + 4 * kb, opart | (sides << 4))
+
+    def relax_colour_masked(self, A, b, x, sor, colour, mask):
+        """the points of `colour` (1..8) where `mask` holds: points of one colour do not couple, so the colour's update of
+        the whole box, kept only where asked, is what relaxing those points alone gives (statement of the boundary-first
+        chain, cedar_amd/dist.py _chain_parity)"""
+        y = x.clone()
+        self.O.relax_colour3_part(self._n(A), self._n(b), self._n(y), self._n(sor), colour, 0)
+        m = torch.from_numpy(mask)
+        x[m] = y[m]
 
     class _Side:  # CPU: no streams, the "side" work simply runs in program order
         def __enter__(self):

@@ -37,7 +37,8 @@ def _worker(rank, world, port, case, outdir):
         import problems as pb
         from cedar_amd.dist import DistSolver3, Topology
         from dist_cpu_backend import CpuBackend
-        kind, n, pgrid, agg = case
+        kind, n, pgrid, agg = case[:4]
+        chain = len(case) > 4 and case[4]
         topo = Topology(rank, world, pgrid)
         gn = tuple(n[d] * topo.p[d] for d in range(3))
         gso, gb = build_global(pb, kind, gn)
@@ -51,7 +52,7 @@ def _worker(rank, world, port, case, outdir):
         b = torch.from_numpy(np.ascontiguousarray(gb[sl])) * m
         x = torch.zeros_like(b)
         # overlap_min=4: the interior-rows-first / deferred y-z halo ordering on every level that has an interior
-        s = DistSolver3(CpuBackend(), topo, A, max_iter=6, agglomerate_below=agg, overlap_min=4)
+        s = DistSolver3(CpuBackend(), topo, A, max_iter=6, agglomerate_below=agg, overlap_min=4, chain=chain)
         h = s.solve(b, x)
         np.save(os.path.join(outdir, f"x{rank}.npy"), x.numpy())
         if rank == 0:
@@ -86,13 +87,23 @@ CASES = [
     ("rand27", (10, 12, 16), (1, 1, 2), 4),
     ("rand27", (9, 7, 8), (1, 1, 4), 2),
     ("fe27", (8, 8, 8), (1, 1, 4), 4),
+    # the boundary-first chain of rank grids with an x / y split (what the native driver runs where a level takes the
+    # partial-sum sweep), stated on the CPU backend: the points next to a neighbouring rank ahead, stage by stage, the rest
+    # of a k-parity afterwards -- neighbour on the low / high / both sides in x and y, with and without a z split
+    ("rand27", (8, 8, 4), (2, 2, 1), 2, True),
+    ("rand27", (16, 8, 6), (2, 1, 1), 2, True),
+    ("rand27", (8, 8, 4), (3, 1, 1), 2, True),
+    ("rand27", (8, 8, 4), (1, 3, 1), 2, True),
+    ("rand27", (8, 16, 4), (1, 2, 2), 2, True),
+    ("rand27", (8, 8, 8), (2, 2, 2), 32, True),
+    ("fe27", (16, 16, 8), (2, 2, 1), 4, True),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-p{'x'.join(map(str, c[2]))}-agg{c[3]}")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[1]))}-p{'x'.join(map(str, c[2]))}-agg{c[3]}" + ("-chain" if len(c) > 4 else ""))
 def test_distributed_equals_single_domain(case, tmp_path, oracle):
     import problems as pb
-    kind, n, pgrid, agg = case
+    kind, n, pgrid, agg = case[:4]
     world = pgrid[0] * pgrid[1] * pgrid[2]
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     gn = tuple(n[d] * pgrid[d] for d in range(3))
