@@ -139,6 +139,107 @@ def test_partial_sum_relax_matches_reference_order_to_rounding(K, oracle, monkey
     assert took == (6 if ny >= 4 * frun else 0)
 
 
+@pytest.mark.parametrize("sides", [(1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1), (1, 1, 1, 1), (1, 0, 0, 1)], ids=str)
+@pytest.mark.parametrize("shape,strip", [((16, 24, 6), True), ((8, 16, 5), False), ((130, 20, 4), True)], ids=str)
+def test_boundary_first_pieces_reorder_the_sweep_without_changing_it(oracle, monkeypatch, shape, strip, sides):
+    """cedar_amd_relax3_rows / _cols / _cols_strip / _planes_masked (the pieces of the distributed sweep on rank grids with
+    an x / y split, dist3.cpp chain_parity) on ONE box without neighbours: the columns and rows that a neighbour on the
+    chosen sides (-x, +x, -y, +y) would make chain points are relaxed ahead, stage by stage, the rest by the masked
+    partial-sum launch.  The order is a valid order of the same Gauss-Seidel sweep, so the result equals the reference
+    sweep to the rounding of the partial sums -- both directions, two sweeps in a row, with and without the dense column
+    copy, neighbours on one, two and all four sides."""
+    import ctypes as C
+    import problems as pb
+    from cedar_amd import capi
+    lib = capi.lib
+    monkeypatch.setenv("CEDAR_AMD_FRUN", "2")
+    nx, ny, nz = shape
+    g = (nz + 2, ny + 2, nx + 2)
+    II, JJ, KK = nx + 2, ny + 2, nz + 2
+    so_h = pb.random_op(g, 14, 91, zero_ghost=False)
+    qf_h, q0 = pb.uniform(g, 92, -1, 1), pb.uniform(g, 93, -1, 1)
+    sor_h = np.zeros((2,) + g)
+    oracle.setup_recip3(so_h, sor_h)
+    so, sor, qf = (capi.DeviceArray.from_numpy(a) for a in (so_h, sor_h, qf_h))
+    VP, U = C.c_void_p, C.c_uint
+    lib.cedar_amd_relax3_prepare.argtypes = [VP, VP, U, U, U]
+    lib.cedar_amd_relax3_release.argtypes = [VP]
+    lib.cedar_amd_relax3_rows.argtypes = [VP, VP, VP, VP, U, U, U] + [C.c_int] * 5
+    lib.cedar_amd_relax3_cols.argtypes = [VP, VP, VP, VP, U, U, U, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.cedar_amd_relax3_cols_strip.argtypes = [VP, VP, VP, VP, U, U, U, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.cedar_amd_relax3_planes_masked.argtypes = [VP, VP, VP, VP, U, U, U, C.c_int, C.c_int, U, U, C.POINTER(C.c_int)]
+    lib.cedar_amd_relax3_strip_doubles.restype = C.c_size_t
+    lib.cedar_amd_relax3_strip_doubles.argtypes = [U, U]
+    lib.cedar_amd_relax3_strip_build.argtypes = [VP, VP, U, U, U, C.c_int, VP]
+    assert lib.cedar_amd_relax3_prepare(so.ptr, sor.ptr, II, JJ, KK) & 2
+    strips = [None, None]
+    if strip:
+        for side in (0, 1):
+            if sides[side]:
+                strips[side] = capi.DeviceArray((lib.cedar_amd_relax3_strip_doubles(JJ, KK),))
+                lib.cedar_amd_relax3_strip_build(so.ptr, sor.ptr, II, JJ, KK, side, strips[side].ptr)
+
+    def cols(q, jb, kb, cl, x0=-1, x1=-1):
+        if not cl:
+            return
+        arr = (C.c_int * len(cl))(*cl)
+        if strip:
+            lib.cedar_amd_relax3_cols_strip(strips[0].ptr if strips[0] else None, strips[1].ptr if strips[1] else None, qf.ptr, q.ptr,
+                                            II, JJ, KK, jb, kb, len(cl), arr, x0, x1)
+        else:
+            lib.cedar_amd_relax3_cols(so.ptr, qf.ptr, q.ptr, sor.ptr, II, JJ, KK, jb, kb, len(cl), arr, x0, x1)
+
+    def parity(q, kb, up):  # dist3.cpp chain_parity without the exchanges
+        jbF = 0 if up else 1
+        c1, c2, colsS, fixc, mF, mS = [], [], [], [], 0, 0
+        for side in (0, 1):
+            if not sides[side]:
+                continue
+            col = (lambda d: nx - d) if side else (lambda d: 1 + d)
+            bit = (lambda d: 1 << (7 - d)) if side else (lambda d: 1 << d)
+            if (side == 0) == up:  # side P
+                c1 += [col(0), col(2)]; c2 += [col(1)]; colsS += [col(0)]
+                mF |= bit(0) | bit(1) | bit(2); mS |= bit(0)
+            else:
+                c1 += [col(1), col(3)]; c2 += [col(2), col(0)]; colsS += [col(1), col(0)]; fixc += [col(0)]
+                mF |= bit(0) | bit(1) | bit(2) | bit(3); mS |= bit(0) | bit(1)
+        rowsF, rowS = [], -1
+        for side in (0, 1):
+            if not sides[2 + side]:
+                continue
+            row = (lambda d: ny - d) if side else (lambda d: 1 + d)
+            if (side == 0) == up:
+                rowsF.append(row(0))
+            else:
+                rowsF.append(row(1)); rowS = row(0)
+        skip = [rowsF[0] if rowsF else -1, rowsF[1] if len(rowsF) > 1 else -1, rowS]
+        if rowsF:
+            lib.cedar_amd_relax3_rows(so.ptr, qf.ptr, q.ptr, sor.ptr, II, JJ, KK, rowsF[0], rowsF[1] - rowsF[0] if len(rowsF) > 1 else 2,
+                                      len(rowsF), kb, int(up))
+        cols(q, jbF, kb, c1 + c2, skip[0], skip[1])
+        cols(q, jbF, kb, fixc)
+        if rowS >= 0:
+            lib.cedar_amd_relax3_rows(so.ptr, qf.ptr, q.ptr, sor.ptr, II, JJ, KK, rowS, 2, 1, kb, int(up))
+        cols(q, 1 - jbF, kb, colsS, rowS, -1)
+        cols(q, 1 - jbF, kb, fixc)
+        assert lib.cedar_amd_relax3_planes_masked(so.ptr, qf.ptr, q.ptr, sor.ptr, II, JJ, KK, kb, int(up), mF, mS, (C.c_int * 3)(*skip)) == 1
+
+    try:
+        for ud in (0, 1):  # BMG_DOWN, BMG_UP
+            up = ud == 1
+            want = q0.copy()
+            q = capi.DeviceArray.from_numpy(q0)
+            for sweep in range(2):
+                oracle.relax3(so_h, qf_h, want, sor_h, 1 if up else 0)
+                for c in range(2):
+                    parity(q, c if up else 1 - c, up)
+                got = q.numpy()
+                scale = np.max(np.abs(want))
+                assert np.max(np.abs(got - want)) <= 2e-14 * (sweep + 1) * scale, (shape, sides, ud, sweep, np.max(np.abs(got - want)) / scale)
+    finally:
+        lib.cedar_amd_relax3_release(so.ptr)
+
+
 @pytest.mark.parametrize("frun", [2, 3, 4])
 @pytest.mark.parametrize("shape", [(300, 48), (131, 33), (1100, 25), (260, 24), (514, 40), (1025, 64), (4096, 33)], ids=str)
 def test_partial_sum_relax9_matches_reference_order_to_rounding(K, oracle, monkeypatch, shape, frun):
