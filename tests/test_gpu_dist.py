@@ -143,6 +143,12 @@ CHAIN_CASES.append(((64, 256, 32), (2, 2, 1)))  # (z deep enough for a four-leve
 CHAIN_IDS.append("4ranks-xy-default-run-length")
 
 
+# rows of 512 points per rank: the 256-lane kernels of the production size (masks on lanes 254 / 255, dense column copy of a
+# 514-point row), three chain levels
+CHAIN_CASES.append(((512, 32, 32), (2, 2, 1)))
+CHAIN_IDS.append("4ranks-xy-512-point-rows")
+
+
 @pytest.mark.parametrize("n,pgrid", CHAIN_CASES, ids=CHAIN_IDS)
 def test_native_driver_boundary_first_chain_equals_single_domain(n, pgrid, tmp_path, oracle, monkeypatch):
     """the partial-sum sweep on rank grids with an x / y split: columns and rows next to a neighbouring rank relaxed ahead,
@@ -150,9 +156,11 @@ def test_native_driver_boundary_first_chain_equals_single_domain(n, pgrid, tmp_p
     if n[1] < 256:
         monkeypatch.setenv("CEDAR_AMD_FRUN", "2")
     world = pgrid[0] * pgrid[1] * pgrid[2]
-    two = n == (32, 32, 16)  # levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered), both on the chain
-    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), 96, "native", 4 if two else 64))
-    assert int(open(tmp_path / "chain_levels.txt").read()) == (2 if two else 1)
+    # agglomerate_below = 4: (32, 32, 16) keeps levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered),
+    # (512, 32, 32) levels 0, 1 and 2 -- all of them on the chain
+    deep = {(32, 32, 16): 2, (512, 32, 32): 3}.get(n)
+    _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), 96, "native", 4 if deep else 64))
+    assert int(open(tmp_path / "chain_levels.txt").read()) == (deep or 1)
     _check_against_single_domain(n, pgrid, tmp_path, oracle)
 
 

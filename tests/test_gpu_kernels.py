@@ -140,7 +140,8 @@ def test_partial_sum_relax_matches_reference_order_to_rounding(K, oracle, monkey
 
 
 @pytest.mark.parametrize("sides", [(1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1), (1, 1, 1, 1), (1, 0, 0, 1)], ids=str)
-@pytest.mark.parametrize("shape,strip", [((16, 24, 6), True), ((8, 16, 5), False), ((130, 20, 4), True)], ids=str)
+@pytest.mark.parametrize("shape,strip", [((16, 24, 6), True), ((8, 16, 5), False), ((130, 20, 4), True), ((512, 16, 4), True),
+                                         ((512, 24, 3), False)], ids=str)
 def test_boundary_first_pieces_reorder_the_sweep_without_changing_it(oracle, monkeypatch, shape, strip, sides):
     """cedar_amd_relax3_rows / _cols / _cols_strip / _planes_masked (the pieces of the distributed sweep on rank grids with
     an x / y split, dist3.cpp chain_parity) on ONE box without neighbours: the columns and rows that a neighbour on the
