@@ -783,9 +783,40 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const real_t *__restric
 	}
 }
 
+// the same with 16-byte accesses on both sides (even extents, 16-byte aligned arrays): a lane moves two neighbouring
+// columns of a row in and two neighbouring rows of a column out
+__global__ __launch_bounds__(256) void transpose2_pairs_kernel(const real_t *__restrict__ in, real_t *__restrict__ out, int II, int JJ,
+                                                               size_t bstride)
+{
+	__shared__ real_t tile[64][65];
+	in += bstride * blockIdx.z; out += bstride * blockIdx.z;
+	const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+	const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5; // 32 pairs x 8
+	for (int r = r0; r < 64; r += 8) {
+		const int i = i0 + 2 * c, j = j0 + r;
+		if (i < II && j < JJ) {
+			const d2u v = *reinterpret_cast<const d2u *>(in + (size_t)i + (size_t)II * j);
+			tile[r][2 * c] = v.x; tile[r][2 * c + 1] = v.y;
+		}
+	}
+	__syncthreads();
+	for (int r = r0; r < 64; r += 8) {
+		const int i = i0 + r, j = j0 + 2 * c;
+		if (i < II && j < JJ) {
+			d2u v; v.x = tile[2 * c][r]; v.y = tile[2 * c + 1][r];
+			*reinterpret_cast<d2u *>(out + (size_t)j + (size_t)JJ * i) = v;
+		}
+	}
+}
+
 void transpose2(const real_t *in, real_t *out, int II, int JJ, hipStream_t st, Batch bt)
 {
-	hipLaunchKernelGGL(transpose2_kernel, dim3((II + 63) / 64, (JJ + 63) / 64, bt.n), dim3(256), 0, st, in, out, II, JJ, bt.stride);
+	// CEDAR_AMD_TRANSPOSE_PAIRS=0: 8-byte accesses (round 2).  8192^2, 49 transposes of a line-xy V-cycle: 2.63 -> 2.28 ms; a
+	// 64 x 128 tile (1 KB output rows, 66 KB of LDS) measured 2.65 ms and was dropped
+	const char *e = getenv("CEDAR_AMD_TRANSPOSE_PAIRS");
+	const bool pairs = !(e && atoi(e) == 0) && !(II & 1) && !(JJ & 1) && !(bt.stride & 1) && !(((uintptr_t)in | (uintptr_t)out) & 15);
+	if (pairs) hipLaunchKernelGGL(transpose2_pairs_kernel, dim3((II + 63) / 64, (JJ + 63) / 64, bt.n), dim3(256), 0, st, in, out, II, JJ, bt.stride);
+	else hipLaunchKernelGGL(transpose2_kernel, dim3((II + 63) / 64, (JJ + 63) / 64, bt.n), dim3(256), 0, st, in, out, II, JJ, bt.stride);
 }
 
 // sot (JJ fast, II, nstncl planes): plane KS = KW^T, KW = KS^T, KSW = KSW^T, KNW = KNW^T; KO is not read by the sweep
