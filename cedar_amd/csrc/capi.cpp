@@ -542,6 +542,14 @@ int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_
 	return relax3_prepare(so, sor, (int)ii, (int)jj, (int)kk, mode <= 0 ? -1 : mode == 1 ? 0 : mode, current_stream());
 }
 
+int cedar_amd_relax3_prepare_rows(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk, int psum_min_rows)
+{
+	if (!is_device_ptr(so) || !is_device_ptr(sor)) return 0;
+	const char *e = getenv("CEDAR_AMD_ILV");
+	const int mode = e ? atoi(e) : 320;
+	return relax3_prepare_rows(so, sor, (int)ii, (int)jj, (int)kk, mode <= 0 ? -1 : mode == 1 ? 0 : mode, psum_min_rows, current_stream());
+}
+
 void cedar_amd_relax3_release(const real_t *so) { relax3_release(so); }
 
 int cedar_amd_relax2_gs_psum(real_t *so, real_t *qf, real_t *q, real_t *sor, len_t ii, len_t jj, int updown)

@@ -301,7 +301,8 @@ void setup(cedar_amd_dist3 *d)
 		// (chain_parity); CEDAR_AMD_DIST_CHAIN=0 keeps the reference-order row-class passes
 		else if (F.nst == 14 && F.n[0] >= 8 && F.n[1] >= 8 && !(getenv("CEDAR_AMD_DIST_CHAIN") && !atoi(getenv("CEDAR_AMD_DIST_CHAIN"))) &&
 		         F.n[1] >= (getenv("CEDAR_AMD_DIST_CHAIN_MIN") ? atoi(getenv("CEDAR_AMD_DIST_CHAIN_MIN")) : 0))
-			F.chain = (cedar_amd_relax3_prepare(F.A, F.sor, F.II, F.JJ, F.KK) & 2) != 0;
+			F.chain = (cedar_amd_relax3_prepare_rows(F.A, F.sor, F.II, F.JJ, F.KK,
+			                                         getenv("CEDAR_AMD_DIST_PSUM_MIN") ? atoi(getenv("CEDAR_AMD_DIST_PSUM_MIN")) : 128) & 2) != 0;
 		if (F.chain && F.n[0] >= 12 && !(getenv("CEDAR_AMD_DIST_STRIP") && !atoi(getenv("CEDAR_AMD_DIST_STRIP"))))
 			for (int side = 0; side < 2; side++)
 				if (has_nb(d, 0, side ? +1 : -1)) {

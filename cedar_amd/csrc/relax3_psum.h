@@ -38,6 +38,9 @@ void relax3_planes27_psum(const Op3 &A, const real_t *qf, real_t *q, real_t *T, 
 // the launch of a rank grid with an x / y split after its boundary-first chain.  false = the level has no partial-sum sweep.
 bool relax3_planes27_masked(const real_t *so, const real_t *qf, real_t *q, const real_t *sor, int II, int JJ, int KK, int kb,
                             int up, const PsumSkip &skip, hipStream_t st);
+// relax3_prepare with the partial-sum sweep registered from psum_min_rows rows on (runs of 8 rows below the levels that take
+// it anyway): relax3_planes27_masked uses the run length fixed here
+int relax3_prepare_rows(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, int psum_min_rows, hipStream_t st);
 // boundary-first chain pieces (relax3d.hip), reference order:
 //   rows j0, j0+jstep, .. (nrj of them) of every plane of parity kb, both i-colours;
 //   the points of the listed columns (0-based offsets, relaxed in the order given) in every row of class jb but xrow0 / xrow1

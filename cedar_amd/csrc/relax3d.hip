@@ -85,19 +85,25 @@ void ilv_build(const real_t *so, const real_t *sor_msor, real_t *ilv, int II, in
 // Solve copies registered for operators that live outside a resident solver (the per-rank arrays of the
 // domain-decomposed solver, cedar_amd/dist.py): the per-piece entry points below look the operator pointer up and read
 // the row-interleaved copy when there is one.  The caller re-registers after it changed the operator.
-struct IlvReg { real_t *ilv, *T; int II, JJ, KK; }; // T: partial-sum scratch of the sweep (relax3d_psum.hip), one vector
+// T: partial-sum scratch of the sweep (relax3d_psum.hip), one vector; frun: its run length on this operator (0: none)
+struct IlvReg { real_t *ilv, *T; int II, JJ, KK, frun; };
 static std::map<const real_t *, IlvReg> g_ilv;
 
-int relax3_prepare(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, hipStream_t st)
+// psum_min_rows > 0: the partial-sum sweep from that many rows on (relax3_prepare_rows: the distributed driver on rank grids
+// with an x / y split, where the alternative is not four row-class launches but four passes with an exchange after each)
+static int prepare_impl(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, int psum_min_rows, hipStream_t st)
 {
 	relax3_release(so);
 	size_t fr = 0, tot = 0;
 	const size_t bytes = ilv_doubles(II, JJ, KK) * sizeof(real_t);
 	const bool want_ilv = min_rows >= 0 && JJ - 2 >= min_rows && (II - 2 + 1) / 2 <= 512 && hipMemGetInfo(&fr, &tot) == hipSuccess
 	                      && bytes + tot / 10 < fr;
-	const bool want_T = relax3_psum_wanted(II, JJ, KK);
+	int frun = relax3_psum_frun(JJ);
+	const char *ep = getenv("CEDAR_AMD_PSUM"), *ef = getenv("CEDAR_AMD_FRUN");
+	if (!frun && psum_min_rows > 0 && JJ - 2 >= psum_min_rows && !ef) frun = 8;
+	const bool want_T = !(ep && atoi(ep) == 0) && relax3_psum_ok(II, JJ, KK, frun);
 	if (!want_ilv && !want_T) return 0;
-	IlvReg r{nullptr, nullptr, II, JJ, KK};
+	IlvReg r{nullptr, nullptr, II, JJ, KK, want_T ? frun : 0};
 	if (want_ilv) {
 		CEDAR_HIP_CHECK(hipMalloc((void **)&r.ilv, bytes));
 		ilv_build(so, sor + (size_t)II * JJ * KK, r.ilv, II, JJ, KK, st);
@@ -105,6 +111,16 @@ int relax3_prepare(const real_t *so, const real_t *sor, int II, int JJ, int KK, 
 	if (want_T) CEDAR_HIP_CHECK(hipMalloc((void **)&r.T, (size_t)II * JJ * KK * sizeof(real_t)));
 	g_ilv[so] = r;
 	return (want_ilv ? 1 : 0) | (want_T ? 2 : 0);
+}
+
+int relax3_prepare(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, hipStream_t st)
+{
+	return prepare_impl(so, sor, II, JJ, KK, min_rows, 0, st);
+}
+
+int relax3_prepare_rows(const real_t *so, const real_t *sor, int II, int JJ, int KK, int min_rows, int psum_min_rows, hipStream_t st)
+{
+	return prepare_impl(so, sor, II, JJ, KK, min_rows, psum_min_rows, st);
 }
 
 void relax3_release(const real_t *so)
@@ -812,8 +828,8 @@ bool relax3_planes27_masked(const real_t *so, const real_t *qf, real_t *q, const
 	const Op3 A = op3_lookup(so, sor, II, JJ, KK);
 	const IlvReg *reg = reg_lookup(so, II, JJ, KK);
 	const int npairs = (II - 2 + 1) / 2, nrk = (KK - 2 - kb + 1) / 2;
-	if (!(reg && reg->T && npairs >= 4 && npairs <= 256 && relax3_psum_wanted(II, JJ, KK))) return false;
-	if (nrk > 0) relax3_planes27_psum(A, qf, q, reg->T, II, JJ, KK, kb, up, 0, nrk, 0, relax3_psum_frun(JJ), st, &skip);
+	if (!(reg && reg->T && reg->frun > 0 && npairs >= 4 && npairs <= 256)) return false;
+	if (nrk > 0) relax3_planes27_psum(A, qf, q, reg->T, II, JJ, KK, kb, up, 0, nrk, 0, reg->frun, st, &skip);
 	return true;
 }
 

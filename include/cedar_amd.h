@@ -170,6 +170,10 @@ void cedar_amd_relax3_planes(real_t *so, real_t *qf, real_t *q, real_t *sor, len
  * scratch vector kept with the registration.  Returns bit 0: a solve copy was made, bit 1: the scratch was.  Call again
  * after the operator changed; release before freeing it.  The resident solver (section 2) does this by itself. */
 int cedar_amd_relax3_prepare(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk);
+/* the same with the partial-sum sweep registered from psum_min_rows rows on (runs of 8 rows below 160 rows) for
+ * cedar_amd_relax3_planes_masked: on a rank grid with an x / y split the alternative to it is not four row-class launches but
+ * four passes with an exchange after each, and the sweep pays from 128 rows on (what cedar_amd_dist3_* registers) */
+int cedar_amd_relax3_prepare_rows(const real_t *so, const real_t *sor, len_t ii, len_t jj, len_t kk, int psum_min_rows);
 void cedar_amd_relax3_release(const real_t *so);
 /* One 27-point sweep (BMG3_SymStd_relax_GS.f90:80-138, Dirichlet) with INTER-PLANE PARTIAL SUMS: the planes of the
  * first k-parity are relaxed in the reference's order and leave, per point of the planes between them, the sums of the

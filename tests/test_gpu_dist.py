@@ -143,6 +143,11 @@ CHAIN_CASES.append(((64, 256, 32), (2, 2, 1)))  # (z deep enough for a four-leve
 CHAIN_IDS.append("4ranks-xy-default-run-length")
 
 
+# 128 rows per rank: below the 160 rows from which a single GPU takes the partial-sum sweep, but on a rank grid with an x / y
+# split the driver registers it from 128 rows on (runs of 8 rows)
+CHAIN_CASES.append(((16, 128, 16), (2, 2, 1)))
+CHAIN_IDS.append("4ranks-xy-128-rows-default-runs")
+DEFAULT_RUNS = {(64, 256, 32), (16, 128, 16)}
 # rows of 512 points per rank: the 256-lane kernels of the production size (masks on lanes 254 / 255, dense column copy of a
 # 514-point row), three chain levels
 CHAIN_CASES.append(((512, 32, 32), (2, 2, 1)))
@@ -153,7 +158,7 @@ CHAIN_IDS.append("4ranks-xy-512-point-rows")
 def test_native_driver_boundary_first_chain_equals_single_domain(n, pgrid, tmp_path, oracle, monkeypatch):
     """the partial-sum sweep on rank grids with an x / y split: columns and rows next to a neighbouring rank relaxed ahead,
     stage by stage, the rest of a k-parity in one masked launch -- the single-domain history and solution"""
-    if n[1] < 256:
+    if n not in DEFAULT_RUNS:
         monkeypatch.setenv("CEDAR_AMD_FRUN", "2")
     world = pgrid[0] * pgrid[1] * pgrid[2]
     # agglomerate_below = 4: (32, 32, 16) keeps levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered),
