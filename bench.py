@@ -21,7 +21,9 @@ Extra keys in the JSON line:
   level0_kernels   N = 1, 3d27: the other level-0 kernels of the cycle (residual27_rows, restrict3, interp_add3) against the
                HBM roofline: algorithmic bytes / launch time from HIP events (cedar_amd_solver_time_op)
   other_workloads  N = 1, default run only: BASELINE configs 2 and 3 (2d9 4096^2 point, 2d9l 8192^2 line-xy) timed the same
-               way in this process after the 3D solver has been released: ms_per_step, DOF/s, relax launch time and frac
+               way in this process after the 3D solver has been released: ms_per_step, DOF/s, relax launch time and frac;
+               3d27_rank_of_2x2x2_loopback: one rank of config 5 (native distributed driver, loop-back transport: kernels,
+               packs and copies of the 8-GPU run per rank, no links) and its ratio to the single-GPU cycle
   ms_per_step_per_allocation  N = 1: the W warm-up + K timed steps are run on every one of the fresh allocations the
                roofline launch time is taken over (default 3), and `value` / `ms_per_step` are the MEDIAN: where the
                operator lands in device memory moves a sweep by +-6 %, and the headline should
@@ -182,6 +184,39 @@ def other_workload(capi, wl, steps=10, warmup=3):
            "relax_achieved_GBps": alg / (lm * 1e-3) / 1e9, "relax_frac": alg / (lm * 1e-3) / 8e12}
     s.close()
     so.free(); b.free(); x.free()
+    return out
+
+
+def rank_of_grid(capi, pgrid=(2, 2, 2), n=512, steps=5, warmup=2):
+    """BASELINE config 5 per rank on the one GPU of this run: the native distributed driver (cedar_amd_dist3_*) as the rank in
+    the middle of a px x py x pz rank grid with the loop-back transport -- every message of the grid is packed, copied in place
+    of the send / receive and unpacked, so the kernels, packs and copies are those of one rank of the 8-GPU run and only the
+    links are missing (the ghost values are this rank's own: a cost figure, not a solve)"""
+    import ctypes as C
+    from cedar_amd.dist3 import DistSolver3
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    centre = tuple(min(1, p - 1) for p in pgrid)
+    rank = centre[2] * pgrid[0] * pgrid[1] + centre[1] * pgrid[0] + centre[0]
+    g = (n + 2, n + 2, n + 2)
+    A, b = capi.DeviceArray((14,) + g), capi.DeviceArray(g)
+    pp = (C.c_double * 6)(0.0, 0.0, 0.0, float(n), float(n), float(n))
+    capi.lib.cedar_amd_gallery(112, A.ptr, b.ptr, n, n, n, pp)
+    s = DistSolver3("loopback", rank, world, A, pgrid=pgrid)
+    x = capi.DeviceArray(g)
+    for _ in range(warmup):
+        s.vcycle(x, b)
+    capi.lib.cedar_amd_device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.vcycle(x, b)
+    t1 = time.perf_counter()
+    capi.lib.cedar_amd_device_sync()
+    t2 = time.perf_counter()
+    out = {"workload": "one rank of a %dx%dx%d rank grid, 3D 27-pt %d^3 per rank, V(2,1), loop-back transport (no links)" % (pgrid + (n,)),
+           "ms_per_step": (t2 - t0) / steps * 1e3, "host_enqueue_ms_per_step": (t1 - t0) / steps * 1e3, "steps": steps, "warmup": warmup,
+           "levels_on_boundary_first_chain": s.chain_levels}
+    s.close()
+    A.free(); b.free(); x.free()
     return out
 
 
@@ -517,6 +552,10 @@ def main():
             solver = None
             so.free(); b.free(); x.free()
             out["other_workloads"] = {wl: other_workload(capi, wl) for wl in ("2d9", "2d9l")}
+            # ... and what one rank of BASELINE config 5 (2x2x2 ranks, 512^3 each) costs beside its links
+            rk = rank_of_grid(capi)
+            rk["vs_single_gpu_ms_per_step"] = rk["ms_per_step"] / out["ms_per_step"]
+            out["other_workloads"]["3d27_rank_of_2x2x2_loopback"] = rk
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, relax)
         print(json.dumps(out), flush=True)
