@@ -553,8 +553,11 @@ def main():
             so.free(); b.free(); x.free()
             out["other_workloads"] = {wl: other_workload(capi, wl) for wl in ("2d9", "2d9l")}
             # ... and what one rank of BASELINE config 5 (2x2x2 ranks, 512^3 each) costs beside its links
-            rk = rank_of_grid(capi)
-            rk["vs_single_gpu_ms_per_step"] = rk["ms_per_step"] / out["ms_per_step"]
+            try:
+                rk = rank_of_grid(capi)
+                rk["vs_single_gpu_ms_per_step"] = rk["ms_per_step"] / out["ms_per_step"]
+            except Exception as e:  # noqa: BLE001 -- an aid beside the headline: its failure must not cost the line
+                rk = {"error": "%s: %s" % (type(e).__name__, e)}
             out["other_workloads"]["3d27_rank_of_2x2x2_loopback"] = rk
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, relax)
