@@ -97,6 +97,7 @@ CASES = [
     ("rand27", (8, 16, 4), (1, 2, 2), 2, True),
     ("rand27", (8, 8, 8), (2, 2, 2), 32, True),
     ("fe27", (16, 16, 8), (2, 2, 1), 4, True),
+    ("rand27", (8, 8, 4), (3, 2, 1), 2, True),
 ]
 
 

@@ -148,6 +148,9 @@ CHAIN_IDS.append("4ranks-xy-default-run-length")
 CHAIN_CASES.append(((16, 128, 16), (2, 2, 1)))
 CHAIN_IDS.append("4ranks-xy-128-rows-default-runs")
 DEFAULT_RUNS = {(64, 256, 32), (16, 128, 16)}
+# six ranks (the most a one-GPU box lets share its card): a rank with neighbours on both sides in x AND one in y
+CHAIN_CASES.append(((16, 16, 8), (3, 2, 1)))
+CHAIN_IDS.append("6ranks-xy")
 # rows of 512 points per rank: the 256-lane kernels of the production size (masks on lanes 254 / 255, dense column copy of a
 # 514-point row), three chain levels
 CHAIN_CASES.append(((512, 32, 32), (2, 2, 1)))
