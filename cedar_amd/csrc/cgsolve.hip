@@ -16,30 +16,43 @@ namespace cedar_amd {
 
 #define ABD(r, c) abd[(size_t)((r)-1) + (size_t)nabd1 * (size_t)((c)-1)]
 
-// DPBTF2 'U' on AB(ldab, n), bandwidth kd; returns LAPACK INFO
-__device__ int dpbtf2_upper(int n, int kd, real_t *ab, int ldab)
+// DPBTF2 'U' on AB(ldab, n), bandwidth kd; returns LAPACK INFO.  Run by a whole workgroup (every thread of the block must
+// call it): a column step is a pivot, a scaling and the rank-one update A := A - x x^T of the trailing band block, whose
+// entries are independent -- each entry receives exactly the operation the sequential loops of DPBTF2 apply to it
+// (a + x_r * (-x_c), two roundings), in the same order over the column steps, so the factor is bit-identical to the
+// sequential routine; the lanes only share the entries of one step.  (One thread running those loops -- rounds 1-3 -- spends
+// 160 s on a 4096 x 1024 band: the coarsest level of an elongated or gathered grid.)
+__device__ int dpbtf2_upper_wg(int n, int kd, real_t *ab, int ldab, int *flag /* LDS */)
 {
 	const int kld = ldab - 1 > 1 ? ldab - 1 : 1;
+	if (threadIdx.x == 0) *flag = 0;
+	__syncthreads();
 	for (int j = 1; j <= n; j++) {
 		real_t *dj = ab + (size_t)kd + (size_t)ldab * (size_t)(j - 1); // AB(kd+1, j)
-		real_t ajj = *dj;
-		if (ajj <= 0.0) return j;
-		ajj = sqrt(ajj);
-		*dj = ajj;
+		if (threadIdx.x == 0) {
+			const real_t ajj = *dj;
+			if (ajj <= 0.0) *flag = j;
+			else *dj = sqrt(ajj);
+		}
+		__syncthreads();
+		if (*flag) return *flag;
 		const int kn = kd < n - j ? kd : n - j;
 		if (kn > 0) {
-			const real_t r = 1.0 / ajj;
-			real_t *x = ab + (size_t)(kd - 1) + (size_t)ldab * (size_t)j;     // AB(kd, j+1), stride kld
-			real_t *a = ab + (size_t)kd + (size_t)ldab * (size_t)j;           // AB(kd+1, j+1), lda kld
-			for (int t = 0; t < kn; t++) x[(size_t)t * kld] = r * x[(size_t)t * kld];
+			const real_t r = 1.0 / *dj;
+			real_t *x = ab + (size_t)(kd - 1) + (size_t)ldab * (size_t)j; // AB(kd, j+1), stride kld
+			real_t *a = ab + (size_t)kd + (size_t)ldab * (size_t)j;       // AB(kd+1, j+1), lda kld
+			for (int t = threadIdx.x; t < kn; t += blockDim.x) x[(size_t)t * kld] = r * x[(size_t)t * kld];
+			__syncthreads();
 			for (int c = 0; c < kn; c++) {
 				const real_t xc = x[(size_t)c * kld];
 				if (xc != 0.0) {
 					const real_t temp = -1.0 * xc;
-					for (int rr = 0; rr <= c; rr++) a[(size_t)rr + (size_t)c * kld] += x[(size_t)rr * kld] * temp;
+					// (x(rr) of this step lies on the super-diagonal line through AB(kd, j+1): never an entry a(rr', c') with rr' <= c')
+					for (int rr = threadIdx.x; rr <= c; rr += blockDim.x) a[(size_t)rr + (size_t)c * kld] += x[(size_t)rr * kld] * temp;
 				}
 			}
 		}
+		__syncthreads();
 	}
 	return 0;
 }
@@ -110,7 +123,9 @@ __global__ __launch_bounds__(256) void setup_cg2_kernel(const real_t *__restrict
 		ABD(1, kk) = nstncl == 5 ? -so[KSW * PS + x] : 0.0;
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) *info = dpbtf2_upper(n, I1, abd, nabd1);
+	__shared__ int flag;
+	const int rc = dpbtf2_upper_wg(n, I1, abd, nabd1, &flag);
+	if (threadIdx.x == 0) *info = rc;
 }
 
 __global__ __launch_bounds__(64) void solve_cg2_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ,
@@ -177,7 +192,9 @@ __global__ __launch_bounds__(256) void setup_cg3_kernel(const real_t *__restrict
 		ABD(1, kl) = full ? -so[KBSW * PS + x] : 0.0;
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) *info = dpbtf2_upper(n, ibw, abd, nabd1);
+	__shared__ int flag;
+	const int rc = dpbtf2_upper_wg(n, ibw, abd, nabd1, &flag);
+	if (threadIdx.x == 0) *info = rc;
 }
 
 __global__ __launch_bounds__(64) void solve_cg3_kernel(real_t *__restrict__ q, const real_t *__restrict__ qf, int II, int JJ, int KK,

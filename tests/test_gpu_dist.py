@@ -151,9 +151,10 @@ DEFAULT_RUNS = {(16, 256, 32), (16, 128, 16)}
 # six ranks (the most a one-GPU box lets share its card): a rank with neighbours on both sides in x AND one in y
 CHAIN_CASES.append(((16, 16, 8), (3, 2, 1)))
 CHAIN_IDS.append("6ranks-xy")
-# (rows of 512 points per rank -- the 256-lane kernels of the production size -- run on one box in tests/test_gpu_kernels.py
-# test_boundary_first_pieces_..: a rank grid with such rows and a coarsest level small enough for the reference-order,
-# single-thread banded Cholesky of the coarse solve would have to be close to 512^3 per rank)
+# rows of 512 points per rank: the 256-lane kernels of the production size (masks on lanes 254 / 255, dense column copy of a
+# 514-point row), two chain levels; the gathered coarsest level has 4096 unknowns in a band of 1024
+CHAIN_CASES.append(((512, 16, 16), (2, 1, 1)))
+CHAIN_IDS.append("2ranks-x-512-point-rows")
 
 
 @pytest.mark.parametrize("n,pgrid", CHAIN_CASES, ids=CHAIN_IDS)
@@ -165,7 +166,7 @@ def test_native_driver_boundary_first_chain_equals_single_domain(n, pgrid, tmp_p
     world = pgrid[0] * pgrid[1] * pgrid[2]
     # agglomerate_below = 4: (32, 32, 16) keeps levels 0 and 1 distributed (level 2, 8 x 8 x 4 per rank, is gathered), both on
     # the chain
-    deep = {(32, 32, 16): 2}.get(n)
+    deep = {(32, 32, 16): 2, (512, 16, 16): 2}.get(n)
     maxit = 5
     _spawn(_worker, world, (_free_port(), n, pgrid, str(tmp_path), 96, "native", 4 if deep else 64, maxit))
     assert int(open(tmp_path / "chain_levels.txt").read()) == (deep or 1)
