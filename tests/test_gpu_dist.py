@@ -148,9 +148,8 @@ CHAIN_IDS.append("4ranks-xy-default-run-length")
 CHAIN_CASES.append(((16, 128, 16), (2, 2, 1)))
 CHAIN_IDS.append("4ranks-xy-128-rows-default-runs")
 DEFAULT_RUNS = {(16, 256, 32), (16, 128, 16)}
-# six ranks (the most a one-GPU box lets share its card): a rank with neighbours on both sides in x AND one in y
-CHAIN_CASES.append(((16, 16, 8), (3, 2, 1)))
-CHAIN_IDS.append("6ranks-xy")
+# (a 3 x 2 x 1 grid -- a rank with neighbours on both sides in x AND one in y -- runs on the CPU statement of the chain,
+# tests/test_dist_cpu.py: six rank processes plus this one would exceed the six a one-GPU box lets share its card)
 # rows of 512 points per rank: the 256-lane kernels of the production size (masks on lanes 254 / 255, dense column copy of a
 # 514-point row), two chain levels; the gathered coarsest level has 4096 unknowns in a band of 1024
 CHAIN_CASES.append(((512, 16, 16), (2, 1, 1)))
